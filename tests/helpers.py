@@ -1,0 +1,34 @@
+"""Shared test helpers: synthetic subjects and golden-trace replay."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+TRACES = ['trace_f32_K4_reward', 'trace_f64_K100', 'trace_f32_K4_n512',
+          'trace_f64_K4_f32affine']
+
+
+def synthetic_subject(D, C=45, seed=1234, peaks=True):
+    """SURVEY 8(d) recipe (same as tests/golden/make_golden.py)."""
+    rng = np.random.RandomState(seed)
+    sh = (0.1 * rng.standard_normal((D, D, D, C))).astype(np.float32)
+    sh[..., 0] = 1.0
+    g = np.indices((D, D, D)).astype(np.float64)
+    r = np.sqrt(((g - (D - 1) / 2.0) ** 2).sum(0))
+    mask = (r < 0.42 * D).astype(np.uint8)
+    pk = rng.standard_normal((D, D, D, 15)).astype(np.float32) if peaks else None
+    if pk is not None:
+        pk[0, 0, 0] = 0.0
+        pk[D // 2, D // 2, D // 2, 3:6] = 0.0
+    return sh, mask, pk
+
+
+def load_trace(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    return z
+
+
+def trace_step_size(z):
+    """The step size with the numpy scalar type the reference held."""
+    return np.dtype(str(z['step_size_dtype'])).type(z['step_size'])
