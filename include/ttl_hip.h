@@ -1,0 +1,180 @@
+/*
+ * ttl_hip.h -- C ABI of libttl_hip.so: the MI355X (gfx950) tractography
+ * environment step.
+ *
+ * The reference (levje/TrackToLearn @ 2024-10-24) is pure Python and has no
+ * FFI layer; the drop-in boundary is the Python class surface of
+ * TrackToLearn/environments/{env,tracking_env,noisy_tracking_env}.py.  The
+ * Python host classes in tracktolearn_amd/environments keep that surface and
+ * bind the entry points below through ctypes (INTEGRATION.md shows the stub).
+ * Each entry point cites the reference code it replaces (paths relative to the
+ * reference root, TTL = TrackToLearn).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, no C++/torch types; return 0 on success, a
+ *     negative TTL_ERR_* otherwise, message via ttl_last_error() (thread
+ *     local).  Nothing throws or aborts across the ABI.
+ *   - every device pointer is BORROWED: the caller (torch, or any hipMalloc
+ *     owner) allocates and outlives the handle.  The library allocates no
+ *     device memory.
+ *   - every call is asynchronous on the caller's HIP stream (`hip_stream` is
+ *     a hipStream_t, NULL = default stream).  The only host-visible outputs
+ *     are the 4-byte counters written through `host_counts` (pinned memory
+ *     supplied by the caller), valid after the stream is synchronised.
+ *   - one host thread per handle; handles share nothing.
+ */
+#ifndef TTL_HIP_H
+#define TTL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTL_ABI_VERSION 1
+
+#define TTL_OK 0
+#define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
+#define TTL_ERR_HIP (-2)     /* a HIP runtime call failed                    */
+#define TTL_ERR_STATE (-3)   /* call order violated (e.g. step before reset) */
+
+/* Direction arithmetic: TTL/environments/env.py:493-502 runs in
+ * float32 for the training env and in float64 for NoisyTrackingEnvironment
+ * (TTL/environments/noisy_tracking_env.py:65-77). */
+#define TTL_MODE_F32 0
+#define TTL_MODE_F64DIR 1
+
+/* StoppingFlags, TTL/environments/stopping_criteria.py:10-20 */
+#define TTL_FLAG_MASK 1
+#define TTL_FLAG_LENGTH 2
+#define TTL_FLAG_CURVATURE 4
+
+/* Row order of the state rows written by ttl_env_step():
+ *   ORDER_ACTIVE    row i of the output = i-th active streamline (the order
+ *                   of continue_idx), exactly tracking_env.py:214-221.
+ *   ORDER_PARTITION survivors first (stable), then the streamlines that just
+ *                   stopped (stable): rows [0, n_continue) are already the
+ *                   harvest() result, so harvest copies nothing.  row_dest[i]
+ *                   maps active row i to its output row. */
+#define TTL_ORDER_ACTIVE 0
+#define TTL_ORDER_PARTITION 1
+
+typedef struct ttl_env_desc {
+    uint32_t abi_version;  /* TTL_ABI_VERSION */
+    int32_t mode;          /* TTL_MODE_*      */
+
+    /* SH volume, packed by ttl_pack_sh_volume(): [X][Y][Z][coef_pitch] f32 */
+    int32_t sh_dim[3];
+    int32_t n_coef;        /* C (45 for SH order 8)                          */
+    int32_t coef_pitch;    /* floats per voxel record, multiple of 4, >= C   */
+    const float *sh_packed;
+    float sh_coord_shift;  /* added to coordinates before the gather; 0.0    */
+                           /* (voxel i sits at coordinate i)  */
+
+    /* tracking mask: cubic B-spline coefficients, [X][Y][Z] f64
+     * (scipy.ndimage.spline_filter(order=3), stopping_criteria.py:58-59)    */
+    int32_t mask_dim[3];
+    const double *mask_coef;
+    double mask_threshold; /* env_dto['binary_stopping_threshold']           */
+
+    /* fODF peaks for the alignment reward: [X][Y][Z][15] f32, or NULL       */
+    int32_t peaks_dim[3];
+    const float *peaks;
+    int32_t compute_reward;
+    double alignment_weighting;
+
+    /* tracking parameters (env.py:196-213) */
+    int32_t n_dirs;        /* K previous directions in the state             */
+    int32_t max_nb_steps;  /* int(max_length / step_size_mm)                 */
+    double step_size_vox;  /* convert_length_mm2vox(step_size_mm, affine)    */
+    float neigh_radius_vox;/* neighbourhood radius (float32, env.py:207-213) */
+    int32_t curvature_enabled;
+    float curv_dot_max;    /* too curvy  <=>  -1 <= dot <= curv_dot_max; the
+                              host derives it from numpy's own float32 arccos
+                              (utils.py:172-173), see curvature_threshold()  */
+
+    /* per-streamline state, capacity n_max rows (tracking_env.py:110-124)   */
+    int32_t n_max;
+    float *streamlines;    /* [n_max][max_nb_steps+1][3] f32                 */
+    int32_t *flags;        /* [n_max] StoppingFlags bitmask                  */
+    int32_t *lengths;      /* [n_max]                                        */
+    uint8_t *dones;        /* [n_max]                                        */
+    int32_t *idx_a;        /* [n_max] continue_idx, double buffered          */
+    int32_t *idx_b;        /* [n_max]                                        */
+    void *workspace;       /* ttl_env_workspace_bytes(n_max) bytes           */
+    size_t workspace_bytes;
+} ttl_env_desc;
+
+typedef struct ttl_env ttl_env;
+
+/* Bytes of device scratch the handle needs for n_max streamlines. */
+size_t ttl_env_workspace_bytes(int32_t n_max);
+
+/* Repack an SH volume [X][Y][Z][C] f32 (the layout of
+ * TTL/environments/env.py:169-180 `data_volume`) into 16-byte aligned voxel
+ * records [X][Y][Z][coef_pitch], zero padded.  Once per subject. */
+int ttl_pack_sh_volume(const float *src, float *dst, int64_t n_voxels,
+                       int32_t n_coef, int32_t coef_pitch, void *hip_stream);
+
+/* Validates the descriptor and creates a handle (no device work).
+ * Replaces the per-subject setup of BaseEnv.load_subject, env.py:143-281. */
+int ttl_env_create(const ttl_env_desc *desc, ttl_env **out);
+void ttl_env_destroy(ttl_env *env);
+
+/* TrackingEnvironment.reset / nreset (tracking_env.py:91-133 / 47-89):
+ * n seeds (float32 [n][3], voxel space) become streamlines 0..n-1 of one
+ * point; flags 0, lengths 1, dones 0, continue_idx = arange(n); writes the
+ * first state rows ([n][state_pitch] f32, state_pitch >= 7*C + 3*K). */
+int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
+                  float *state_out, int64_t state_pitch, void *hip_stream);
+
+/* TrackingEnvironment.step (tracking_env.py:135-221) for the n_active
+ * streamlines of continue_idx (n_active must equal the count the last
+ * reset/harvest reported):
+ *   actions   [n_active][3] f32 (row i belongs to continue_idx[i])
+ *   noise     [n_active][3] f64 added to the action first (F64DIR mode,
+ *             noisy_tracking_env.py:73-77), or NULL for +0.0
+ *   state_out [n_active][state_pitch] f32, row order per `order`
+ *   reward_out[n_active] f64 or NULL  (row i = active row i, always)
+ *   done_out  [n_active] u8           (row i = active row i, always)
+ * Normalise + scale the action, first-step flip, grow by one point, LENGTH /
+ * CURVATURE / MASK stopping tests, flags and dones, alignment reward, new
+ * state.  continue_idx itself only changes in ttl_env_harvest(). */
+int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
+                 int32_t n_active, int32_t order, float *state_out,
+                 int64_t state_pitch, double *reward_out, uint8_t *done_out,
+                 void *hip_stream);
+
+/* TrackingEnvironment.harvest (tracking_env.py:223-245): lengths of the
+ * streamlines that stopped in the last step, continue_idx <- survivors
+ * (stable).  If the last step used ORDER_ACTIVE and state_out != NULL the
+ * survivors' rows are copied from state_in (the step's output) to the first
+ * n_continue rows of state_out.  host_counts (pinned, 2 x int32) receives
+ * {n_continue, n_stopped} once the stream has run. */
+int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
+                    int64_t state_pitch, int32_t *host_counts,
+                    void *hip_stream);
+
+/* BaseEnv._compute_stopping_flags (env.py:567-603) on caller-supplied points:
+ * tail [n][3][3] f32 holds the last three points (oldest first) of n
+ * streamlines that have n_points points each (with n_points == 2 the first
+ * entry of a tail is ignored, with n_points == 1 the first two are).
+ * flags_out[n] u8 = OR of TTL_FLAG_* (0 = keeps going).  Touches no env state. */
+int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
+                           int32_t n_points, uint8_t *flags_out,
+                           void *hip_stream);
+
+/* Current continue_idx buffer (device, int32 [n_active]) and, after a step,
+ * the active-row -> output-row map (device, int32 [n_active]). */
+int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
+                 const int32_t **row_dest, int32_t *length);
+
+const char *ttl_last_error(void);
+uint32_t ttl_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTL_HIP_H */

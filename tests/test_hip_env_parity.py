@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP environment (through the C ABI) against
+ (a) the golden traces captured from the reference, and
+ (b) the CPU oracle on seeded random inputs.
+
+Bars (BASELINE.json north_star): stopping masks / indices / flags / lengths
+bit-exact; positions, states and rewards within 1e-5.  Positions are in fact
+required to be bit-identical here (IEEE arithmetic in the reference's order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TRACES, load_trace, synthetic_subject, trace_step_size
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _dto(*, n_dirs, theta=30.0, max_length, reward, noise=0.0, thr=0.1):
+    return dict(n_dirs=n_dirs, theta=theta, npv=1,
+                binary_stopping_threshold=thr, step_size=0.75, min_length=2.0,
+                max_length=max_length, compute_reward=reward,
+                alignment_weighting=1.0, oracle_bonus=0.0,
+                oracle_checkpoint=None, oracle_stopping_criterion=False,
+                rng=np.random.RandomState(0), device=torch.device('cuda:0'),
+                target_sh_order=8, noise=noise, fa_map=None)
+
+
+def _hip_env(D, *, noisy, affine_dtype, seeds, **kw):
+    from tracktolearn_amd.datasets.utils import MRIDataVolume as Vol
+    from tracktolearn_amd.environments import (NoisyTrackingEnvironment,
+                                               TrackingEnvironment)
+    sh, mask, pk = synthetic_subject(D)
+    aff = np.eye(4, dtype=affine_dtype)
+    subject = (Vol(sh, aff), Vol(mask.astype(np.float32), aff),
+               Vol(mask.astype(np.float32), aff), Vol(pk, aff), None)
+    cls = NoisyTrackingEnvironment if noisy else TrackingEnvironment
+    env = cls(subject, 'testing', _dto(**kw))
+    env.seeds = seeds
+    return env
+
+
+def _env_from_trace(z):
+    max_length = float(z['max_nb_steps']) * 0.75 + 0.01
+    aff = np.float32 if str(z['step_size_dtype']) == 'float32' else np.float64
+    env = _hip_env(int(z['D']), noisy=bool(z['noisy']), affine_dtype=aff,
+                   seeds=z['seeds'], n_dirs=int(z['n_dirs']),
+                   theta=float(z['theta']), max_length=max_length,
+                   reward=bool(z['reward']))
+    assert env.max_nb_steps == int(z['max_nb_steps'])
+    assert env.step_size == trace_step_size(z)
+    assert np.array_equal(env._mask_coef.cpu().numpy(), z['mask_coef'])
+    return env
+
+
+def _close(a, b, tol=TOL):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    both_nan = np.isnan(a) & np.isnan(b)
+    return np.all((np.abs(a - b) <= tol) | both_nan)
+
+
+@pytest.mark.parametrize('name', TRACES)
+def test_reference_trace_step_harvest(name):
+    """step()/harvest() -- the reference's calling contract."""
+    z = load_trace(name)
+    env = _env_from_trace(z)
+    N = z['seeds'].shape[0]
+    state = env.reset(0, N)
+    assert state.dtype == torch.float32 and state.is_cuda
+    assert _close(state.cpu().numpy(), z['state_reset'])
+    for s in range(int(z['n_steps'])):
+        assert np.array_equal(env.continue_idx, z[f'continue_idx_{s}'])
+        nstate, rew, done, info = env.step(z[f'actions_{s}'].copy())
+        assert done.dtype == bool and np.array_equal(done, z[f'dones_{s}'])
+        assert np.array_equal(info['continue_idx'], z[f'continue_idx_{s}'])
+        assert np.array_equal(env.flags, z[f'flags_{s}'])
+        assert rew.dtype == np.float64 and rew.shape == z[f'reward_{s}'].shape
+        assert _close(rew, z[f'reward_{s}'])
+        if bool(z['reward']):
+            assert abs(info['reward_info']['peaks_reward'] -
+                       float(z[f'reward_info_peaks_{s}'])) <= TOL
+        idx = z[f'continue_idx_{s}']
+        head = env.streamlines[idx, env.length - 1]
+        assert np.array_equal(head, z[f'head_{s}'])         # bit-identical
+        ns = nstate.cpu().numpy()
+        if f'state_{s}' in z.files:
+            assert _close(ns, z[f'state_{s}'])
+        assert np.abs(ns.astype(np.float64).sum(axis=1) -
+                      z[f'state_rowsum_{s}']).max() <= 327 * TOL
+        hstate, not_stopping = env.harvest()
+        assert np.array_equal(not_stopping, ~z[f'dones_{s}'])
+        assert hstate.shape[0] == int(z[f'harvest_rows_{s}'])
+        assert torch.equal(hstate, nstate[torch.from_numpy(~z[f'dones_{s}'])])
+        assert np.array_equal(env.lengths, z[f'lengths_{s}'])
+        assert np.array_equal(env.continue_idx, z[f'new_continue_idx_{s}'])
+    assert np.array_equal(env.streamlines, z['streamlines'])
+    tg = env.get_streamlines()
+    assert np.array_equal([len(s) for s in tg.streamlines], z['tract_lengths'])
+    assert np.array_equal(np.concatenate(tg.streamlines), z['tract_points'])
+    assert np.array_equal(tg.data_per_streamline['flags'], z['tract_flags'])
+    assert np.array_equal(tg.data_per_streamline['seeds'], z['tract_seeds'])
+
+
+@pytest.mark.parametrize('name', TRACES)
+def test_reference_trace_device_loop(name):
+    """step_device()/harvest(): survivors-first rows, nothing leaves the GPU
+    except the 8-byte counters."""
+    z = load_trace(name)
+    env = _env_from_trace(z)
+    N = z['seeds'].shape[0]
+    env.reset(0, N)
+    for s in range(int(z['n_steps'])):
+        acts = torch.from_numpy(z[f'actions_{s}']).cuda()
+        nstate, rew, done, info = env.step_device(acts)
+        dest = info['row_dest'].cpu().numpy()
+        done_np = done.cpu().numpy().astype(bool)
+        assert np.array_equal(done_np, z[f'dones_{s}'])
+        # row_dest is the stable partition: survivors, then stopped
+        n_keep = int((~done_np).sum())
+        want = np.empty(len(done_np), np.int64)
+        want[~done_np] = np.arange(n_keep)
+        want[done_np] = n_keep + np.arange(len(done_np) - n_keep)
+        assert np.array_equal(dest, want)
+        ns = nstate.cpu().numpy()[dest]          # back to active-row order
+        if f'state_{s}' in z.files:
+            assert _close(ns, z[f'state_{s}'])
+        if bool(z['reward']):
+            assert _close(rew.cpu().numpy(), z[f'reward_{s}'])
+        hstate, not_stopping = env.harvest()
+        assert hstate.data_ptr() == nstate.data_ptr()      # a view, no copy
+        assert hstate.shape[0] == int(z[f'harvest_rows_{s}'])
+        assert np.array_equal(not_stopping.cpu().numpy(), ~z[f'dones_{s}'])
+        assert np.array_equal(env.continue_idx, z[f'new_continue_idx_{s}'])
+        assert np.array_equal(env.lengths, z[f'lengths_{s}'])
+        assert np.array_equal(env.flags, z[f'flags_{s}'])
+    assert np.array_equal(env.streamlines, z['streamlines'])
+
+
+def test_isolated_stopping_vectors():
+    """Adversarial curvature triples (angles within 1e-6 rad of theta, zero
+    length and reversed segments) and mask points on / next to every border,
+    against the reference's recorded decisions."""
+    z = load_trace('isolated_functions')
+    D = z['mask_in'].shape[0]
+    env = _hip_env(D, noisy=False, affine_dtype=np.float32,
+                   seeds=np.zeros((1, 3)), n_dirs=4,
+                   theta=float(z['curvy_theta']), max_length=1000.0,
+                   reward=False)
+    assert np.array_equal(env._mask_coef.cpu().numpy(), z['mask_coef'])
+    # mask: single-point streamlines
+    pts = z['mask_pts']
+    stop, flags = env._compute_stopping_flags(pts[:, None, :])
+    assert np.array_equal(stop, z['mask_stop'])
+    assert set(np.unique(flags)) <= {0, 1}
+    # curvature: 3-point streamlines deep inside the mask region are also
+    # tested by the mask, so compare only the curvature bit
+    tri = z['curvy_in']
+    _, flags = env._compute_stopping_flags(tri)
+    assert np.array_equal((flags & 4) != 0, z['curvy_out'])
+
+
+def _scripted(rng, state_np, n_sh, step, wobble):
+    n = state_np.shape[0]
+    if step == 0:
+        return rng.standard_normal((n, 3)).astype(np.float32)
+    prev = state_np[:, n_sh:n_sh + 3].astype(np.float64)
+    nrm = np.linalg.norm(prev, axis=1, keepdims=True)
+    nrm[nrm == 0] = 1.0
+    return (prev / nrm + wobble * rng.standard_normal((n, 3))).astype(np.float32)
+
+
+@pytest.mark.parametrize('noisy,affine,K,reward', [
+    (False, np.float32, 4, True),
+    (True, np.float64, 100, False),
+    (False, np.float64, 4, False),      # plain env, f64 affine: numpy-2 promotion
+])
+def test_random_episode_against_oracle(noisy, affine, K, reward):
+    """4096 streamlines on a 24^3 volume, scripted actions, run to exhaustion:
+    HIP env vs CPU oracle step by step."""
+    from oracle import env_oracle as orc
+    D, N = 24, 4096
+    sh, mask, pk = synthetic_subject(D)
+    rng = np.random.RandomState(11)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    max_length = 30.0
+    env = _hip_env(D, noisy=noisy, affine_dtype=affine, seeds=seeds, n_dirs=K,
+                   max_length=max_length, reward=reward)
+    kw = dict(n_dirs=K, theta=30.0, step_size=env.step_size,
+              max_nb_steps=env.max_nb_steps, mask_threshold=0.1, peaks=pk,
+              compute_reward=reward, alignment_weighting=1.0)
+    ref = (orc.OracleNoisyTrackingEnv(sh, mask, seeds, noise=0.0, **kw) if noisy
+           else orc.OracleTrackingEnv(sh, mask, seeds, **kw))
+    s_hip = env.reset(0, N)
+    s_ref = ref.reset(0, N)
+    assert _close(s_hip.cpu().numpy(), s_ref)
+    step = 0
+    seen = 0
+    while len(ref.continue_idx):
+        a = _scripted(rng, s_ref, 7 * 45, step, 0.2)
+        ns_hip, r_hip, d_hip, _ = env.step(a.copy())
+        ns_ref, r_ref, d_ref, _ = ref.step(a.copy())
+        assert np.array_equal(d_hip, d_ref)
+        assert _close(ns_hip.cpu().numpy(), ns_ref)
+        assert _close(r_hip, r_ref)
+        s_hip, _ = env.harvest()
+        s_ref, _ = ref.harvest()
+        assert np.array_equal(env.continue_idx, ref.continue_idx)
+        seen |= int(np.bitwise_or.reduce(ref.flags))
+        step += 1
+    assert np.array_equal(env.flags, ref.flags)
+    assert np.array_equal(env.lengths, ref.lengths)
+    assert np.array_equal(env.streamlines, ref.streamlines)   # bit-identical
+    assert seen == 7          # MASK, LENGTH and CURVATURE all exercised
+
+
+def test_edge_cases():
+    """Single streamline, zero action (NaN direction -> mask stop), seeds
+    outside the volume, ragged re-use of a larger handle."""
+    from oracle import env_oracle as orc
+    D = 12
+    sh, mask, pk = synthetic_subject(D)
+    seeds = np.array([[5.5, 5.5, 5.5], [-3.0, 2.0, 2.0], [5.0, 6.0, 40.0],
+                      [0.2, 0.3, 11.2], [6.0, 6.0, 6.0]])
+    env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds,
+                   n_dirs=4, max_length=20.0, reward=True)
+    ref = orc.OracleTrackingEnv(
+        sh, mask, seeds, n_dirs=4, theta=30.0, step_size=env.step_size,
+        max_nb_steps=env.max_nb_steps, mask_threshold=0.1, peaks=pk,
+        compute_reward=True, alignment_weighting=1.0)
+    for (a, b) in [(0, 5), (0, 1), (1, 4)]:        # shrinking batches re-use buffers
+        s_hip, s_ref = env.reset(a, b), ref.reset(a, b)
+        assert _close(s_hip.cpu().numpy(), s_ref)
+        n = b - a
+        acts = np.tile(np.array([[1.0, 0.5, -0.25]], np.float32), (n, 1))
+        acts[0] = 0.0                               # zero action -> NaN step
+        with np.errstate(all='ignore'):
+            ns_ref, r_ref, d_ref, _ = ref.step(acts.copy())
+        ns_hip, r_hip, d_hip, _ = env.step(acts.copy())
+        assert np.array_equal(d_hip, d_ref)
+        assert d_hip[0]                             # NaN position leaves the mask
+        assert _close(ns_hip.cpu().numpy(), ns_ref)
+        assert _close(r_hip, r_ref)
+        env.harvest()
+        ref.harvest()
+        assert np.array_equal(env.flags, ref.flags)
+        assert np.array_equal(env.continue_idx, ref.continue_idx)
+    assert env.get_state_size() == 7 * 45 + 12

@@ -1,0 +1,131 @@
+"""CPU-only tests of the host logic and of the C-ABI library surface (no
+compute call: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import load_trace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tracktolearn_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'ttl_hip.h')).read()
+    body = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(ttl_[a-z_]+)\s*\(', body))
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ttl_abi_version() == _lib.ABI_VERSION
+    assert lib.ttl_env_workspace_bytes(1024) > 1024 * 13
+
+
+def test_descriptor_layout_matches_header():
+    """ctypes struct mirrors the C struct field for field (names, order)."""
+    from tracktolearn_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'ttl_hip.h')).read()
+    struct = header[header.index('typedef struct ttl_env_desc {'):
+                    header.index('} ttl_env_desc;')]
+    struct = re.sub(r'/\*.*?\*/', '', struct, flags=re.S)
+    names = re.findall(r'\b\**([a-z_0-9]+)(?:\[3\])?;', struct)
+    assert names == [f[0] for f in _lib.EnvDesc._fields_]
+
+
+def test_create_rejects_bad_descriptors():
+    """Argument validation happens on the host, before any device work."""
+    from tracktolearn_amd import _lib
+    lib = _lib.load()
+    d = _lib.EnvDesc()
+    h = ctypes.c_void_p()
+    assert lib.ttl_env_create(ctypes.byref(d), ctypes.byref(h)) == -1
+    assert b'abi_version' in lib.ttl_last_error()
+    d.abi_version = _lib.ABI_VERSION
+    d.mode = 7
+    assert lib.ttl_env_create(ctypes.byref(d), ctypes.byref(h)) == -1
+    assert b'mode' in lib.ttl_last_error()
+    assert lib.ttl_env_step(None, None, None, 1, 0, None, 0, None, None, None) == -1
+    assert lib.ttl_pack_sh_volume(None, None, 1, 1, 4, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from tracktolearn_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libttl_hip.so')
+    with pytest.raises(_lib.TTLError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_env_refuses_cpu_device():
+    import torch
+    from tracktolearn_amd.datasets.utils import MRIDataVolume
+    from tracktolearn_amd.environments import TrackingEnvironment
+    vol = MRIDataVolume(np.zeros((4, 4, 4, 45), np.float32), np.eye(4))
+    dto = dict(n_dirs=4, theta=30, npv=1, binary_stopping_threshold=0.1,
+               step_size=0.75, min_length=20, max_length=200,
+               compute_reward=False, alignment_weighting=1, rng=None,
+               device=torch.device('cpu'))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        TrackingEnvironment((vol, vol, vol, None, None), 'testing', dto)
+
+
+def test_curvature_threshold_equals_numpy_arccos_decision():
+    """The dot-product threshold reproduces the reference's golden curvature
+    decisions (2048 triples, most of them within 1e-6 rad of theta)."""
+    from tracktolearn_amd.environments.stopping_criteria import \
+        curvature_dot_threshold
+    z = load_trace('isolated_functions')
+    tri = z['curvy_in']
+    with np.errstate(all='ignore'):
+        d1 = tri[:, 2] - tri[:, 1]
+        d0 = tri[:, 1] - tri[:, 0]
+        u = d1 / np.sqrt(np.einsum('...i,...i', d1, d1))[..., None]
+        v = d0 / np.sqrt(np.einsum('...i,...i', d0, d0))[..., None]
+        dot = np.einsum('ij,ij->i', u, v)
+        c, enabled = curvature_dot_threshold(float(z['curvy_theta']))
+        mine = (dot <= c) & (dot >= -1)
+    assert enabled
+    assert np.array_equal(mine, z['curvy_out'])
+    # exhaustive check of the step property near the boundary
+    bits = np.array([c], np.float32).view(np.int32)[0]
+    xs = (bits + np.arange(-5000, 5000)).astype(np.int32).view(np.float32)
+    assert np.array_equal(np.arccos(xs) > np.deg2rad(float(z['curvy_theta'])),
+                          xs <= c)
+    assert curvature_dot_threshold(200)[1] is False
+
+
+def test_flag_helpers_and_length_conversion():
+    from tracktolearn_amd.environments.stopping_criteria import (
+        StoppingFlags, count_flags, is_flag_set)
+    from tracktolearn_amd.datasets.utils import convert_length_mm2vox
+    flags = np.array([0, 1, 2, 4, 5, 6, 64])
+    assert list(is_flag_set(flags, StoppingFlags.STOPPING_MASK)) == \
+        [False, True, False, False, True, False, False]
+    assert count_flags(flags, StoppingFlags.STOPPING_CURVATURE) == 3
+    s32 = convert_length_mm2vox(0.75, np.eye(4, dtype=np.float32))
+    s64 = convert_length_mm2vox(0.75, np.eye(4))
+    assert s32.dtype == np.float32 and s64.dtype == np.float64
+    with pytest.raises(ValueError):
+        convert_length_mm2vox(1.0, np.diag([1.0, 2.0, 1.0, 1.0]))
+
+
+def test_tractogram_container():
+    from tracktolearn_amd.tractogram import Tractogram
+    a = Tractogram([np.zeros((3, 3), np.float32), np.ones((2, 3), np.float32)],
+                   {'flags': np.array([1, 4]), 'seeds': np.zeros((2, 3))})
+    b = Tractogram([np.full((4, 3), 2, np.float32)],
+                   {'flags': np.array([2]), 'seeds': np.ones((1, 3))})
+    a += b
+    assert len(a) == 3 and list(a.data_per_streamline['flags']) == [1, 4, 2]
+    items = list(a)
+    assert items[2].streamline.shape == (4, 3)
+    assert items[1].data_for_streamline['flags'] == 4
+    A = np.diag([2.0, 2.0, 2.0, 1.0])
+    A[:3, 3] = 1
+    a.apply_affine(A)
+    assert np.allclose(a.streamlines[1], 3.0)

@@ -1,0 +1,108 @@
+"""ctypes binding of libttl_hip.so (C ABI: include/ttl_hip.h).
+
+There is no CPU fallback: if the shared library is missing or does not load,
+``load()`` raises.  Build it with ``python -m tracktolearn_amd.csrc.build``
+(or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
+
+ABI_VERSION = 1
+MODE_F32 = 0
+MODE_F64DIR = 1
+ORDER_ACTIVE = 0
+ORDER_PARTITION = 1
+
+
+class TTLError(RuntimeError):
+    pass
+
+
+class EnvDesc(C.Structure):
+    """struct ttl_env_desc (include/ttl_hip.h) -- field order is the ABI."""
+    _fields_ = [
+        ('abi_version', C.c_uint32),
+        ('mode', C.c_int32),
+        ('sh_dim', C.c_int32 * 3),
+        ('n_coef', C.c_int32),
+        ('coef_pitch', C.c_int32),
+        ('sh_packed', C.c_void_p),
+        ('sh_coord_shift', C.c_float),
+        ('mask_dim', C.c_int32 * 3),
+        ('mask_coef', C.c_void_p),
+        ('mask_threshold', C.c_double),
+        ('peaks_dim', C.c_int32 * 3),
+        ('peaks', C.c_void_p),
+        ('compute_reward', C.c_int32),
+        ('alignment_weighting', C.c_double),
+        ('n_dirs', C.c_int32),
+        ('max_nb_steps', C.c_int32),
+        ('step_size_vox', C.c_double),
+        ('neigh_radius_vox', C.c_float),
+        ('curvature_enabled', C.c_int32),
+        ('curv_dot_max', C.c_float),
+        ('n_max', C.c_int32),
+        ('streamlines', C.c_void_p),
+        ('flags', C.c_void_p),
+        ('lengths', C.c_void_p),
+        ('dones', C.c_void_p),
+        ('idx_a', C.c_void_p),
+        ('idx_b', C.c_void_p),
+        ('workspace', C.c_void_p),
+        ('workspace_bytes', C.c_size_t),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ttl_hip.h declares
+SYMBOLS = {
+    'ttl_env_workspace_bytes': (C.c_size_t, [C.c_int32]),
+    'ttl_pack_sh_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_int32, C.c_void_p]),
+    'ttl_env_create': (C.c_int, [C.POINTER(EnvDesc), C.POINTER(C.c_void_p)]),
+    'ttl_env_destroy': (None, [C.c_void_p]),
+    'ttl_env_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                C.c_int64, C.c_void_p]),
+    'ttl_env_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    'ttl_env_harvest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_void_p]),
+    'ttl_env_stopping_flags': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.c_void_p]),
+    'ttl_env_view': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    'ttl_last_error': (C.c_char_p, []),
+    'ttl_abi_version': (C.c_uint32, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libttl_hip.so once; raise if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TTLError(
+            f'{LIB_PATH} not found: the HIP extension is required (build it '
+            'with `python -m tracktolearn_amd.csrc.build`); there is no CPU '
+            'fallback')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ttl_abi_version() != ABI_VERSION:
+        raise TTLError('libttl_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = load().ttl_last_error().decode('utf-8', 'replace')
+        raise TTLError(f'{what} failed ({code}): {msg}')

@@ -1,0 +1,59 @@
+"""Build libttl_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m tracktolearn_amd.csrc.build [--force]
+
+The shared library is written next to the package (tracktolearn_amd/
+libttl_hip.so) so that it travels with the source tree; it is git-ignored.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+SOURCES = [os.path.join(HERE, 'ttl_hip.hip')]
+HEADERS = [os.path.join(ROOT, 'include', 'ttl_hip.h')]
+OUTPUT = os.path.join(PKG, 'libttl_hip.so')
+
+FLAGS = [
+    '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-std=c++17',
+    # the stopping decisions must round like NumPy/SciPy: never fuse a*b+c,
+    # IEEE divide and sqrt, no fast-math
+    '-ffp-contract=off', '-fno-fast-math',
+    '-fhip-fp32-correctly-rounded-divide-sqrt',
+    '-Wall', '-Wno-unused-function',
+]
+
+
+def find_hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'),
+                 '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (set HIPCC=/path/to/hipcc)')
+
+
+def up_to_date():
+    if not os.path.exists(OUTPUT):
+        return False
+    t = os.path.getmtime(OUTPUT)
+    deps = SOURCES + HEADERS + [os.path.abspath(__file__)]
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and up_to_date():
+        return OUTPUT
+    cmd = [find_hipcc()] + FLAGS + ['-I', os.path.join(ROOT, 'include')] + \
+        SOURCES + ['-o', OUTPUT]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUTPUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(OUTPUT)

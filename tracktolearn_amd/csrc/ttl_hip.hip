@@ -1,0 +1,856 @@
+// ttl_hip.hip -- MI355X (gfx950 / CDNA4) kernels and C ABI for the vectorised
+// tractography environment step.  Written for wave64 only; built with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// (contraction off: the stopping decisions must round exactly like the
+// NumPy/SciPy arithmetic of the reference, which never fuses a*b+c).
+//
+// What runs where (reference = levje/TrackToLearn, TTL = TrackToLearn):
+//   k_advance  : TTL/environments/env.py:493-502 (_format_actions),
+//                noisy_tracking_env.py:73-77 (f64 noise add),
+//                tracking_env.py:165-183 (first-step flip, position update),
+//                env.py:567-603 + utils.py:127-173 + stopping_criteria.py:79-82
+//                (LENGTH / CURVATURE / MASK tests, flags, dones),
+//                reward.py:46-79 + local_reward.py:29-107 (alignment reward),
+//                and the wave-ballot survivor ranks for the compaction.
+//   k_prefix   : tracking_env.py:192-195 / 238-241 (stable index compaction:
+//                new_continue_idx = continue_idx[~stopping]).
+//   k_state    : env.py:504-565 (_format_state): 7-point trilinear gather of
+//                the SH volume + last K segment vectors.
+//   k_finish   : tracking_env.py:236 (lengths[stopping_idx] = length).
+//   k_copy_rows: tracking_env.py:245 (state[continue_idx]).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ttl_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess)                                                \
+            return fail(TTL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int BLOCK = 256;
+
+// Device-side view of the environment (a flat copy of the descriptor).
+struct EnvParams {
+    int mode;
+    int sh_dim[3];
+    int n_coef;
+    int coef_pitch;
+    const float *sh;
+    float sh_shift;
+    int mask_dim[3];
+    const double *mask_coef;
+    double mask_thr;
+    int peaks_dim[3];
+    const float *peaks;
+    int compute_reward;
+    float align_w;
+    int n_dirs;
+    int max_nb_steps;
+    double step64;
+    float step32;
+    float radius;
+    int curv_enabled;
+    float curv_dot_max;
+    float *hist;
+    int *flags;
+    int *lengths;
+    uint8_t *dones;
+    // workspace
+    uint8_t *stop;     // [n_max] 1 = stopped in the last step
+    int *rank;         // [n_max] survivors before this row inside its block
+    int *surv_pos;     // [n_max] position among survivors, -1 if stopped
+    int *row_dest;     // [n_max] state row written for this active row
+    int *block_counts; // [ceil(n_max/BLOCK)] survivors per block
+    int *counts;       // {n_continue, n_stopped}
+};
+
+// ---------------------------------------------------------------------------
+// mask test: scipy.ndimage.map_coordinates(coef, p - 0.5, order=3,
+// mode='constant', cval=0, prefilter=False) < thr, restated tap for tap
+// (oracle/env_oracle.py: spline3_sample).  float64, sequential
+// accumulation, no FMA.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int mirror_fold(int i, int n) {
+    if (n <= 1) return 0;
+    const int s2 = 2 * n - 2;
+    if (i < 0) {
+        i = s2 * ((-i) / s2) + i;
+        i = (i <= 1 - n) ? i + s2 : -i;
+    } else if (i >= n) {
+        i -= s2 * (i / s2);
+        if (i >= n) i = s2 - i;
+    }
+    return i;
+}
+
+__device__ __forceinline__ void cubic_weights(double c, double fl, double *w) {
+    const double y = c - fl;
+    const double z = 1.0 - y;
+    w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+    w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+    w[0] = z * z * z / 6.0;
+    w[3] = 1.0 - w[0] - w[1] - w[2];
+}
+
+__device__ bool outside_mask(const EnvParams &P, float px, float py, float pz) {
+    // coords = streamlines[:, -1, :].T - 0.5 : float32 subtraction
+    const double cx = (double)(px - 0.5f);
+    const double cy = (double)(py - 0.5f);
+    const double cz = (double)(pz - 0.5f);
+    const int nx = P.mask_dim[0], ny = P.mask_dim[1], nz = P.mask_dim[2];
+    // outside [0, n-1] on any axis (or NaN) -> constant 0.0
+    const bool inside = (cx >= 0.0 && cx <= (double)(nx - 1)) &&
+                        (cy >= 0.0 && cy <= (double)(ny - 1)) &&
+                        (cz >= 0.0 && cz <= (double)(nz - 1));
+    if (!inside) return 0.0 < P.mask_thr;
+    const double fx = floor(cx), fy = floor(cy), fz = floor(cz);
+    double wx[4], wy[4], wz[4];
+    cubic_weights(cx, fx, wx);
+    cubic_weights(cy, fy, wy);
+    cubic_weights(cz, fz, wz);
+    const int sx = (int)fx - 1, sy = (int)fy - 1, sz = (int)fz - 1;
+    int ix[4], iy[4], iz[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ix[j] = mirror_fold(sx + j, nx) * ny;
+        iy[j] = mirror_fold(sy + j, ny);
+        iz[j] = mirror_fold(sz + j, nz);
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double *line = P.mask_coef + (size_t)(ix[a] + iy[b]) * nz;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                double v = line[iz[d]];
+                v = v * wx[a];
+                v = v * wy[b];
+                v = v * wz[d];
+                t = t + v;
+            }
+        }
+    }
+    return t < P.mask_thr;
+}
+
+// normalize_vectors on one float32 3-vector: v / sqrt((x*x + y*y) + z*z)
+__device__ __forceinline__ void unit3(float x, float y, float z, float &ox,
+                                      float &oy, float &oz) {
+    const float s = sqrtf((x * x + y * y) + z * z);
+    ox = x / s;
+    oy = y / s;
+    oz = z / s;
+}
+
+// numpy.nan_to_num on float32
+__device__ __forceinline__ float nan_to_num(float v) {
+    if (v != v) return 0.0f;
+    if (v == INFINITY) return 3.4028234663852886e38f;
+    if (v == -INFINITY) return -3.4028234663852886e38f;
+    return v;
+}
+
+// BaseEnv._compute_stopping_flags (env.py:567-603) for one streamline of n_pts
+// points whose last three points are p0, p1, p2 (oldest first): LENGTH
+// (utils.py:142), CURVATURE (utils.py:162-173), MASK
+// (stopping_criteria.py:79-82).  Also returns the unit last segment u and
+// unit previous segment w (zero when n_pts < 3) for the reward.
+__device__ __forceinline__ int stopping_bits(
+    const EnvParams &P, float p0x, float p0y, float p0z, float p1x, float p1y,
+    float p1z, float p2x, float p2y, float p2z, int n_pts, float &ux, float &uy,
+    float &uz, float &wx, float &wy, float &wz) {
+    int bits = 0;
+    if (n_pts >= P.max_nb_steps) bits |= TTL_FLAG_LENGTH;
+    // segments are recomputed in float32 from the stored positions
+    unit3(p2x - p1x, p2y - p1y, p2z - p1z, ux, uy, uz);
+    wx = wy = wz = 0.f;
+    if (n_pts >= 3) {
+        unit3(p1x - p0x, p1y - p0y, p1z - p0z, wx, wy, wz);
+        if (P.curv_enabled) {
+            const float dot = (ux * wx + uy * wy) + uz * wz;
+            // arccos(dot) > theta  <=>  -1 <= dot <= curv_dot_max (NaN and
+            // |dot| > 1 give NaN angles -> not curvy)
+            if (dot <= P.curv_dot_max && dot >= -1.0f) bits |= TTL_FLAG_CURVATURE;
+        }
+    }
+    if (outside_mask(P, p2x, p2y, p2z)) bits |= TTL_FLAG_MASK;
+    return bits;
+}
+
+// ---------------------------------------------------------------------------
+// k_advance: one thread per active streamline.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_advance(
+    EnvParams P, const int *__restrict__ idx, const float *__restrict__ actions,
+    const double *__restrict__ noise, int n_active, int L,
+    double *__restrict__ reward_out, uint8_t *__restrict__ done_out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < n_active;
+    bool stop = false;
+    if (active) {
+        const int g = idx[i];
+        float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
+        const float p1x = h[(L - 1) * 3 + 0];
+        const float p1y = h[(L - 1) * 3 + 1];
+        const float p1z = h[(L - 1) * 3 + 2];
+        const float ax = actions[(size_t)i * 3 + 0];
+        const float ay = actions[(size_t)i * 3 + 1];
+        const float az = actions[(size_t)i * 3 + 2];
+
+        float p2x, p2y, p2z;
+        if (MODE == TTL_MODE_F32) {
+            // directions = normalize_vectors(actions) * step_size   (float32)
+            const float s = sqrtf((ax * ax + ay * ay) + az * az);
+            float dx = (ax / s) * P.step32;
+            float dy = (ay / s) * P.step32;
+            float dz = (az / s) * P.step32;
+            if (L == 1) {
+                const float tx = p1x + dx, ty = p1y + dy, tz = p1z + dz;
+                const bool flip =
+                    (2 >= P.max_nb_steps) || outside_mask(P, tx, ty, tz);
+                if (flip) {
+                    dx = -dx;
+                    dy = -dy;
+                    dz = -dz;
+                }
+            }
+            p2x = p1x + dx;
+            p2y = p1y + dy;
+            p2z = p1z + dz;
+        } else {
+            // float64: (actions + noise) -> normalise -> * step_size; the new
+            // point is float32(float64(p) + d)
+            double a0 = (double)ax, a1 = (double)ay, a2 = (double)az;
+            if (noise) {
+                a0 = a0 + noise[(size_t)i * 3 + 0];
+                a1 = a1 + noise[(size_t)i * 3 + 1];
+                a2 = a2 + noise[(size_t)i * 3 + 2];
+            } else {
+                a0 = a0 + 0.0;
+                a1 = a1 + 0.0;
+                a2 = a2 + 0.0;
+            }
+            const double s = sqrt((a0 * a0 + a1 * a1) + a2 * a2);
+            double dx = (a0 / s) * P.step64;
+            double dy = (a1 / s) * P.step64;
+            double dz = (a2 / s) * P.step64;
+            if (L == 1) {
+                const float tx = (float)((double)p1x + dx);
+                const float ty = (float)((double)p1y + dy);
+                const float tz = (float)((double)p1z + dz);
+                const bool flip =
+                    (2 >= P.max_nb_steps) || outside_mask(P, tx, ty, tz);
+                if (flip) {
+                    dx = -dx;
+                    dy = -dy;
+                    dz = -dz;
+                }
+            }
+            p2x = (float)((double)p1x + dx);
+            p2y = (float)((double)p1y + dy);
+            p2z = (float)((double)p1z + dz);
+        }
+        h[L * 3 + 0] = p2x;
+        h[L * 3 + 1] = p2y;
+        h[L * 3 + 2] = p2z;
+
+        const int n_pts = L + 1;
+        float p0x = 0.f, p0y = 0.f, p0z = 0.f;
+        if (n_pts >= 3) {
+            p0x = h[(L - 2) * 3 + 0];
+            p0y = h[(L - 2) * 3 + 1];
+            p0z = h[(L - 2) * 3 + 2];
+        }
+        float ux, uy, uz, wx, wy, wz;
+        const int bits = stopping_bits(P, p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y,
+                                       p2z, n_pts, ux, uy, uz, wx, wy, wz);
+
+        stop = bits != 0;
+        if (stop) {
+            P.flags[g] = bits;
+            P.dones[g] = 1;
+        }
+        done_out[i] = stop ? 1 : 0;
+
+        if (reward_out) {
+            double rew = 0.0;
+            if (P.compute_reward && P.align_w > 0.0f) {
+                // peaks at int32(p[-2]) (truncation), clipped
+                int vi = (int)p1x, vj = (int)p1y, vk = (int)p1z;
+                vi = min(max(vi, 0), P.peaks_dim[0] - 1);
+                vj = min(max(vj, 0), P.peaks_dim[1] - 1);
+                vk = min(max(vk, 0), P.peaks_dim[2] - 1);
+                const float *pk =
+                    P.peaks +
+                    (((size_t)vi * P.peaks_dim[1] + vj) * P.peaks_dim[2] + vk) * 15;
+                const float u0 = nan_to_num(ux), u1 = nan_to_num(uy),
+                            u2 = nan_to_num(uz);
+                float best = 0.f;  // np.amax over the 5 peaks (NaN sticks)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    float vx, vy, vz;
+                    unit3(pk[3 * k], pk[3 * k + 1], pk[3 * k + 2], vx, vy, vz);
+                    vx = nan_to_num(vx);
+                    vy = nan_to_num(vy);
+                    vz = nan_to_num(vz);
+                    const float d = fabsf((vx * u0 + vy * u1) + vz * u2);
+                    if (k == 0)
+                        best = d;
+                    else if (best == best && (d != d || d > best))
+                        best = d;
+                }
+                float r32 = best;
+                if (n_pts >= 3) {
+                    const double f = ((double)u0 * (double)nan_to_num(wx) +
+                                      (double)u1 * (double)nan_to_num(wy)) +
+                                     (double)u2 * (double)nan_to_num(wz);
+                    r32 = (float)((double)r32 * f);
+                }
+                rew = (double)(P.align_w * r32);
+            }
+            reward_out[i] = rew;
+        }
+        P.stop[i] = stop ? 1 : 0;
+    }
+
+    // wave-ballot survivor ranks (stable): 64-bit ballot per wavefront,
+    // popcount of the lanes below, then the 4 wave totals through LDS.
+    const bool keep = active && !stop;
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int below = __popcll(m & ((1ull << lane) - 1ull));
+    __shared__ int wave_total[BLOCK / 64];
+    if (lane == 0) wave_total[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w)
+        if (w < wave) before += wave_total[w];
+    if (active) P.rank[i] = before + below;
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) tot += wave_total[w];
+        P.block_counts[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_prefix: exclusive prefix over the per-block survivor counts (each block
+// sums its predecessors; <= a few thousand ints from L2), then the stable
+// scatter of continue_idx and the active-row -> state-row map.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
+                                                  const int *__restrict__ idx,
+                                                  int *__restrict__ idx_next,
+                                                  int n_active, int n_blocks,
+                                                  int order) {
+    __shared__ int red[2][BLOCK / 64];
+    int before = 0, total = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += BLOCK) {
+        const int c = P.block_counts[b];
+        total += c;
+        if (b < (int)blockIdx.x) before += c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_down(before, off);
+        total += __shfl_down(total, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = before;
+        red[1][wave] = total;
+    }
+    __syncthreads();
+    before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        before += red[0][w];
+        total += red[1][w];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.counts[0] = total;
+        P.counts[1] = n_active - total;
+    }
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_active) return;
+    const int pos = before + P.rank[i];
+    const bool stop = P.stop[i] != 0;
+    if (!stop) idx_next[pos] = idx[i];
+    P.surv_pos[i] = stop ? -1 : pos;
+    int dest = i;
+    if (order == TTL_ORDER_PARTITION) dest = stop ? total + (i - pos) : pos;
+    P.row_dest[i] = dest;
+}
+
+// ---------------------------------------------------------------------------
+// k_state: LPS lanes per streamline, lane = one float4 column of the padded
+// voxel record, so a group reads each 16B-aligned voxel record as one
+// contiguous coef_pitch*4-byte segment.  7 points x 8 corners accumulate in
+// registers (no cross-lane traffic); the previous-direction block is written
+// by the same lanes.
+// ---------------------------------------------------------------------------
+template <int LPS>
+__global__ __launch_bounds__(BLOCK) void k_state(
+    EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
+    int n_rows, int L, float *__restrict__ out, long long pitch) {
+    constexpr int ROWS = BLOCK / LPS;
+    const int row = blockIdx.x * ROWS + threadIdx.x / LPS;
+    const int sub = threadIdx.x % LPS;
+    if (row >= n_rows) return;
+    const int g = idx ? idx[row] : row;
+    const int r = row_dest ? row_dest[row] : row;
+    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
+    const float px = h[(L - 1) * 3 + 0];
+    const float py = h[(L - 1) * 3 + 1];
+    const float pz = h[(L - 1) * 3 + 2];
+    float *orow = out + (size_t)r * (size_t)pitch;
+    const int C = P.n_coef;
+    const int C4 = P.coef_pitch >> 2;
+    const int X = P.sh_dim[0], Y = P.sh_dim[1], Z = P.sh_dim[2];
+    const float4 *vol = reinterpret_cast<const float4 *>(P.sh);
+
+    for (int c4 = sub; c4 < C4; c4 += LPS) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            // neighbourhood point: [0, +x, +y, +z, -x, -y, -z] * radius
+            const float ox = (k == 1) ? P.radius : (k == 4) ? -P.radius : 0.0f;
+            const float oy = (k == 2) ? P.radius : (k == 5) ? -P.radius : 0.0f;
+            const float oz = (k == 3) ? P.radius : (k == 6) ? -P.radius : 0.0f;
+            float x = px + ox, y = py + oy, z = pz + oz;
+            if (P.sh_shift != 0.0f) {
+                x += P.sh_shift;
+                y += P.sh_shift;
+                z += P.sh_shift;
+            }
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const float dx = x - fx, dy = y - fy, dz = z - fz;
+            // clip the corner indices, not the weights (edge replication);
+            // the float clamp also tames NaN / huge coordinates
+            const int ix0 = (int)fminf(fmaxf(fx, -1.0f), (float)X);
+            const int iy0 = (int)fminf(fmaxf(fy, -1.0f), (float)Y);
+            const int iz0 = (int)fminf(fmaxf(fz, -1.0f), (float)Z);
+            const int xa = min(max(ix0, 0), X - 1), xb = min(max(ix0 + 1, 0), X - 1);
+            const int ya = min(max(iy0, 0), Y - 1), yb = min(max(iy0 + 1, 0), Y - 1);
+            const int za = min(max(iz0, 0), Z - 1), zb = min(max(iz0 + 1, 0), Z - 1);
+            const float ex = 1.0f - dx, ey = 1.0f - dy, ez = 1.0f - dz;
+            const size_t ra = ((size_t)xa * Y + ya) * Z, rb = ((size_t)xa * Y + yb) * Z;
+            const size_t rc = ((size_t)xb * Y + ya) * Z, rd = ((size_t)xb * Y + yb) * Z;
+            // corner order 000,001,010,011,100,101,110,111 (x,y,z bits)
+            const float4 v0 = vol[(ra + za) * C4 + c4];
+            const float4 v1 = vol[(ra + zb) * C4 + c4];
+            const float4 v2 = vol[(rb + za) * C4 + c4];
+            const float4 v3 = vol[(rb + zb) * C4 + c4];
+            const float4 v4 = vol[(rc + za) * C4 + c4];
+            const float4 v5 = vol[(rc + zb) * C4 + c4];
+            const float4 v6 = vol[(rd + za) * C4 + c4];
+            const float4 v7 = vol[(rd + zb) * C4 + c4];
+            const float w0 = (ex * ey) * ez, w1 = (ex * ey) * dz;
+            const float w2 = (ex * dy) * ez, w3 = (ex * dy) * dz;
+            const float w4 = (dx * ey) * ez, w5 = (dx * ey) * dz;
+            const float w6 = (dx * dy) * ez, w7 = (dx * dy) * dz;
+            float4 a;
+#define TTL_ACC(comp)                                                        \
+    a.comp = v0.comp * w0;                                                   \
+    a.comp = a.comp + v1.comp * w1;                                          \
+    a.comp = a.comp + v2.comp * w2;                                          \
+    a.comp = a.comp + v3.comp * w3;                                          \
+    a.comp = a.comp + v4.comp * w4;                                          \
+    a.comp = a.comp + v5.comp * w5;                                          \
+    a.comp = a.comp + v6.comp * w6;                                          \
+    a.comp = a.comp + v7.comp * w7;
+            TTL_ACC(x) TTL_ACC(y) TTL_ACC(z) TTL_ACC(w)
+#undef TTL_ACC
+            const int c = c4 * 4;
+            float *o = orow + k * C + c;
+            if (c + 0 < C) o[0] = a.x;
+            if (c + 1 < C) o[1] = a.y;
+            if (c + 2 < C) o[2] = a.z;
+            if (c + 3 < C) o[3] = a.w;
+        }
+    }
+    // previous directions, most recent first, zero padded (np.diff of the
+    // stored float32 positions)
+    float *od = orow + 7 * C;
+    const int n_seg = L - 1;
+    for (int f = sub; f < 3 * P.n_dirs; f += LPS) {
+        const int j = f / 3, comp = f - 3 * j;
+        float v = 0.0f;
+        if (j < n_seg) v = h[(L - 1 - j) * 3 + comp] - h[(L - 2 - j) * 3 + comp];
+        od[f] = v;
+    }
+}
+
+// stopping flags of caller-supplied tails (n_pts points per streamline)
+__global__ __launch_bounds__(BLOCK) void k_probe_flags(
+    EnvParams P, const float *__restrict__ tail, int n, int n_pts,
+    uint8_t *__restrict__ out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float *t = tail + (size_t)i * 9;
+    float ux, uy, uz, wx, wy, wz;
+    int bits;
+    if (n_pts >= 2) {
+        bits = stopping_bits(P, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
+                             t[8], n_pts, ux, uy, uz, wx, wy, wz);
+    } else {  // a single point: no segment, only LENGTH and MASK can fire
+        bits = (n_pts >= P.max_nb_steps) ? TTL_FLAG_LENGTH : 0;
+        if (outside_mask(P, t[6], t[7], t[8])) bits |= TTL_FLAG_MASK;
+    }
+    out[i] = (uint8_t)bits;
+}
+
+// lengths[stopping_idx] = length
+__global__ __launch_bounds__(BLOCK) void k_finish(EnvParams P,
+                                                  const int *__restrict__ idx,
+                                                  int n_active, int n_pts) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_active) return;
+    if (P.stop[i]) P.lengths[idx[i]] = n_pts;
+}
+
+// state[continue_idx]: copy the survivors' rows to their compacted position
+__global__ __launch_bounds__(BLOCK) void k_copy_rows(
+    EnvParams P, int n_active, int width, const float *__restrict__ in,
+    float *__restrict__ out, long long pitch) {
+    constexpr int LPS = 64;
+    const int row = blockIdx.x * (BLOCK / LPS) + threadIdx.x / LPS;
+    const int sub = threadIdx.x % LPS;
+    if (row >= n_active) return;
+    const int pos = P.surv_pos[row];
+    if (pos < 0) return;
+    const float *src = in + (size_t)row * (size_t)pitch;
+    float *dst = out + (size_t)pos * (size_t)pitch;
+    for (int f = sub; f < width; f += LPS) dst[f] = src[f];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_reset(EnvParams P, int *idx,
+                                                 const float *__restrict__ seeds,
+                                                 int n) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float *h = P.hist + (size_t)i * (size_t)(P.max_nb_steps + 1) * 3;
+    h[0] = seeds[(size_t)i * 3 + 0];
+    h[1] = seeds[(size_t)i * 3 + 1];
+    h[2] = seeds[(size_t)i * 3 + 2];
+    P.flags[i] = 0;
+    P.lengths[i] = 1;
+    P.dones[i] = 0;
+    idx[i] = i;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pack_sh(const float *__restrict__ src,
+                                                   float *__restrict__ dst,
+                                                   long long n_vox, int C,
+                                                   int pitch) {
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long total = n_vox * pitch;
+    if (t >= total) return;
+    const long long v = t / pitch;
+    const int c = (int)(t - v * pitch);
+    dst[t] = (c < C) ? src[v * C + c] : 0.0f;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct ttl_env {
+    ttl_env_desc d;
+    EnvParams P;
+    int length;      // points per active streamline (reference: self.length)
+    int n_active;    // rows of the current continue_idx
+    int cur;         // 0: idx_a is continue_idx, 1: idx_b
+    int stepped;     // a step is waiting for its harvest
+    int last_order;
+    int last_n;      // n_active of the pending step
+};
+
+extern "C" {
+
+const char *ttl_last_error(void) { return g_err; }
+uint32_t ttl_abi_version(void) { return TTL_ABI_VERSION; }
+
+size_t ttl_env_workspace_bytes(int32_t n_max) {
+    if (n_max < 0) return 0;
+    const size_t n = (size_t)n_max;
+    const size_t nb = (n + BLOCK - 1) / BLOCK + 1;
+    size_t b = 0;
+    b += align_up(n, 256);                    // stop
+    b += 3 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest
+    b += align_up(nb * sizeof(int), 256);     // block_counts
+    b += 256;                                 // counts
+    return b;
+}
+
+int ttl_pack_sh_volume(const float *src, float *dst, int64_t n_voxels,
+                       int32_t n_coef, int32_t coef_pitch, void *hip_stream) {
+    if (!src || !dst || n_voxels <= 0 || n_coef <= 0 || coef_pitch < n_coef ||
+        (coef_pitch & 3))
+        return fail(TTL_ERR_INVALID, "ttl_pack_sh_volume: bad arguments");
+    if (((uintptr_t)dst) & 15)
+        return fail(TTL_ERR_INVALID, "ttl_pack_sh_volume: dst must be 16B aligned");
+    const long long total = (long long)n_voxels * coef_pitch;
+    const long long blocks = (total + BLOCK - 1) / BLOCK;
+    if (blocks > 0x7fffffffLL)
+        return fail(TTL_ERR_INVALID, "ttl_pack_sh_volume: volume too large");
+    hipLaunchKernelGGL(k_pack_sh, dim3((unsigned)blocks), dim3(BLOCK), 0,
+                       (hipStream_t)hip_stream, src, dst, (long long)n_voxels,
+                       n_coef, coef_pitch);
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
+}
+
+int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
+    if (!desc || !out) return fail(TTL_ERR_INVALID, "ttl_env_create: null argument");
+    const ttl_env_desc &d = *desc;
+    if (d.abi_version != TTL_ABI_VERSION)
+        return fail(TTL_ERR_INVALID, "ttl_env_create: abi_version %u != %u",
+                    d.abi_version, TTL_ABI_VERSION);
+    if (d.mode != TTL_MODE_F32 && d.mode != TTL_MODE_F64DIR)
+        return fail(TTL_ERR_INVALID, "ttl_env_create: bad mode %d", d.mode);
+    for (int a = 0; a < 3; ++a) {
+        if (d.sh_dim[a] <= 0 || d.mask_dim[a] <= 0)
+            return fail(TTL_ERR_INVALID, "ttl_env_create: non-positive volume dim");
+        if (d.compute_reward && d.peaks_dim[a] <= 0)
+            return fail(TTL_ERR_INVALID, "ttl_env_create: non-positive peaks dim");
+    }
+    if (d.n_coef <= 0 || d.coef_pitch < d.n_coef || (d.coef_pitch & 3))
+        return fail(TTL_ERR_INVALID, "ttl_env_create: coef_pitch must be a multiple of 4 >= n_coef");
+    if (!d.sh_packed || (((uintptr_t)d.sh_packed) & 15))
+        return fail(TTL_ERR_INVALID, "ttl_env_create: sh_packed null or not 16B aligned");
+    if (!d.mask_coef || (((uintptr_t)d.mask_coef) & 7))
+        return fail(TTL_ERR_INVALID, "ttl_env_create: mask_coef null or misaligned");
+    if (d.compute_reward && !d.peaks)
+        return fail(TTL_ERR_INVALID, "ttl_env_create: compute_reward without peaks");
+    if (d.n_dirs < 0 || d.max_nb_steps < 1 || d.n_max < 1)
+        return fail(TTL_ERR_INVALID, "ttl_env_create: bad n_dirs/max_nb_steps/n_max");
+    if (!(d.step_size_vox > 0.0))
+        return fail(TTL_ERR_INVALID, "ttl_env_create: step_size_vox must be > 0");
+    if (!d.streamlines || !d.flags || !d.lengths || !d.dones || !d.idx_a || !d.idx_b)
+        return fail(TTL_ERR_INVALID, "ttl_env_create: null state buffer");
+    if (!d.workspace || d.workspace_bytes < ttl_env_workspace_bytes(d.n_max) ||
+        (((uintptr_t)d.workspace) & 255))
+        return fail(TTL_ERR_INVALID, "ttl_env_create: workspace too small or not 256B aligned");
+
+    ttl_env *e = new (std::nothrow) ttl_env;
+    if (!e) return fail(TTL_ERR_INVALID, "ttl_env_create: out of host memory");
+    e->d = d;
+    EnvParams &P = e->P;
+    memset(&P, 0, sizeof(P));
+    P.mode = d.mode;
+    for (int a = 0; a < 3; ++a) {
+        P.sh_dim[a] = d.sh_dim[a];
+        P.mask_dim[a] = d.mask_dim[a];
+        P.peaks_dim[a] = d.peaks_dim[a];
+    }
+    P.n_coef = d.n_coef;
+    P.coef_pitch = d.coef_pitch;
+    P.sh = d.sh_packed;
+    P.sh_shift = d.sh_coord_shift;
+    P.mask_coef = d.mask_coef;
+    P.mask_thr = d.mask_threshold;
+    P.peaks = d.peaks;
+    P.compute_reward = d.compute_reward;
+    P.align_w = (float)d.alignment_weighting;
+    P.n_dirs = d.n_dirs;
+    P.max_nb_steps = d.max_nb_steps;
+    P.step64 = d.step_size_vox;
+    P.step32 = (float)d.step_size_vox;
+    P.radius = d.neigh_radius_vox;
+    P.curv_enabled = d.curvature_enabled;
+    P.curv_dot_max = d.curv_dot_max;
+    P.hist = d.streamlines;
+    P.flags = d.flags;
+    P.lengths = d.lengths;
+    P.dones = d.dones;
+    const size_t n = (size_t)d.n_max;
+    const size_t nb = (n + BLOCK - 1) / BLOCK + 1;
+    char *w = (char *)d.workspace;
+    P.stop = (uint8_t *)w;        w += align_up(n, 256);
+    P.rank = (int *)w;            w += align_up(n * sizeof(int), 256);
+    P.surv_pos = (int *)w;        w += align_up(n * sizeof(int), 256);
+    P.row_dest = (int *)w;        w += align_up(n * sizeof(int), 256);
+    P.block_counts = (int *)w;    w += align_up(nb * sizeof(int), 256);
+    P.counts = (int *)w;
+    e->length = 0;
+    e->n_active = 0;
+    e->cur = 0;
+    e->stepped = 0;
+    e->last_order = TTL_ORDER_ACTIVE;
+    e->last_n = 0;
+    *out = e;
+    return TTL_OK;
+}
+
+void ttl_env_destroy(ttl_env *env) { delete env; }
+
+static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
+                        int n_rows, int L, float *out, int64_t pitch,
+                        hipStream_t s) {
+    const int C4 = env->P.coef_pitch >> 2;
+#define TTL_LAUNCH_STATE(LPS)                                                 \
+    hipLaunchKernelGGL((k_state<LPS>),                                        \
+                       dim3((n_rows + (BLOCK / LPS) - 1) / (BLOCK / LPS)),    \
+                       dim3(BLOCK), 0, s, env->P, idx, row_dest, n_rows, L,   \
+                       out, (long long)pitch)
+    if (C4 <= 4) TTL_LAUNCH_STATE(4);
+    else if (C4 <= 8) TTL_LAUNCH_STATE(8);
+    else if (C4 <= 16) TTL_LAUNCH_STATE(16);
+    else TTL_LAUNCH_STATE(32);
+#undef TTL_LAUNCH_STATE
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
+}
+
+int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n, float *state_out,
+                  int64_t state_pitch, void *hip_stream) {
+    if (!env || !seeds || !state_out)
+        return fail(TTL_ERR_INVALID, "ttl_env_reset: null argument");
+    const ttl_env_desc &d = env->d;
+    if (n < 1 || n > d.n_max)
+        return fail(TTL_ERR_INVALID, "ttl_env_reset: n=%d outside [1, %d]", n, d.n_max);
+    const int64_t width = 7LL * d.n_coef + 3LL * d.n_dirs;
+    if (state_pitch < width)
+        return fail(TTL_ERR_INVALID, "ttl_env_reset: state_pitch %lld < %lld",
+                    (long long)state_pitch, (long long)width);
+    hipStream_t s = (hipStream_t)hip_stream;
+    const size_t hist_bytes = (size_t)n * (size_t)(d.max_nb_steps + 1) * 3 * sizeof(float);
+    HIP_TRY(hipMemsetAsync(d.streamlines, 0, hist_bytes, s));
+    hipLaunchKernelGGL(k_reset, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
+                       env->P, d.idx_a, seeds, n);
+    HIP_TRY(hipGetLastError());
+    env->cur = 0;
+    env->length = 1;
+    env->n_active = n;
+    env->stepped = 0;
+    return launch_state(env, nullptr, nullptr, n, 1, state_out, state_pitch, s);
+}
+
+int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
+                 int32_t n_active, int32_t order, float *state_out,
+                 int64_t state_pitch, double *reward_out, uint8_t *done_out,
+                 void *hip_stream) {
+    if (!env || !actions || !state_out || !done_out)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
+    if (env->length < 1) return fail(TTL_ERR_STATE, "ttl_env_step: reset first");
+    if (env->stepped) return fail(TTL_ERR_STATE, "ttl_env_step: harvest the previous step first");
+    if (n_active < 1 || n_active > env->n_active)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: n_active=%d outside [1, %d]",
+                    n_active, env->n_active);
+    if (order != TTL_ORDER_ACTIVE && order != TTL_ORDER_PARTITION)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: bad order %d", order);
+    const ttl_env_desc &d = env->d;
+    if (env->length > d.max_nb_steps)
+        return fail(TTL_ERR_STATE, "ttl_env_step: streamline history is full");
+    const int64_t width = 7LL * d.n_coef + 3LL * d.n_dirs;
+    if (state_pitch < width)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: state_pitch too small");
+    if (noise && d.mode != TTL_MODE_F64DIR)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: noise needs TTL_MODE_F64DIR");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int *idx = env->cur ? d.idx_b : d.idx_a;
+    int *idx_next = env->cur ? d.idx_a : d.idx_b;
+    const int L = env->length;
+    const int nb = (n_active + BLOCK - 1) / BLOCK;
+    if (d.mode == TTL_MODE_F32)
+        hipLaunchKernelGGL((k_advance<TTL_MODE_F32>), dim3(nb), dim3(BLOCK), 0, s,
+                           env->P, idx, actions, noise, n_active, L, reward_out,
+                           done_out);
+    else
+        hipLaunchKernelGGL((k_advance<TTL_MODE_F64DIR>), dim3(nb), dim3(BLOCK), 0,
+                           s, env->P, idx, actions, noise, n_active, L,
+                           reward_out, done_out);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
+                       n_active, nb, order);
+    HIP_TRY(hipGetLastError());
+    env->length = L + 1;
+    env->stepped = 1;
+    env->last_order = order;
+    env->last_n = n_active;
+    return launch_state(env, idx, env->P.row_dest, n_active, L + 1, state_out,
+                        state_pitch, s);
+}
+
+int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
+                    int64_t state_pitch, int32_t *host_counts, void *hip_stream) {
+    if (!env || !host_counts)
+        return fail(TTL_ERR_INVALID, "ttl_env_harvest: null argument");
+    if (!env->stepped) return fail(TTL_ERR_STATE, "ttl_env_harvest: no step to harvest");
+    const ttl_env_desc &d = env->d;
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int *idx = env->cur ? d.idx_b : d.idx_a;
+    const int n = env->last_n;
+    const int nb = (n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(k_finish, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, n,
+                       env->length);
+    HIP_TRY(hipGetLastError());
+    if (env->last_order == TTL_ORDER_ACTIVE && state_out) {
+        if (!state_in)
+            return fail(TTL_ERR_INVALID, "ttl_env_harvest: state_in needed to compact rows");
+        const int width = 7 * d.n_coef + 3 * d.n_dirs;
+        hipLaunchKernelGGL(k_copy_rows, dim3((n + 3) / 4), dim3(BLOCK), 0, s, env->P,
+                           n, width, state_in, state_out, (long long)state_pitch);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(host_counts, env->P.counts, 2 * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, s));
+    env->cur ^= 1;
+    env->stepped = 0;
+    // the caller learns the exact survivor count from host_counts; until then
+    // the bound is the previous count
+    env->n_active = n;
+    return TTL_OK;
+}
+
+int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
+                           int32_t n_points, uint8_t *flags_out,
+                           void *hip_stream) {
+    if (!env || !tail || !flags_out)
+        return fail(TTL_ERR_INVALID, "ttl_env_stopping_flags: null argument");
+    if (n < 1 || n_points < 1)
+        return fail(TTL_ERR_INVALID, "ttl_env_stopping_flags: n and n_points must be >= 1");
+    hipLaunchKernelGGL(k_probe_flags, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
+                       (hipStream_t)hip_stream, env->P, tail, n, n_points,
+                       flags_out);
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
+}
+
+int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
+                 const int32_t **row_dest, int32_t *length) {
+    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_view: null handle");
+    if (continue_idx) *continue_idx = env->cur ? env->d.idx_b : env->d.idx_a;
+    if (row_dest) *row_dest = env->P.row_dest;
+    if (length) *length = env->length;
+    return TTL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,284 @@
+"""BaseEnv: per-subject setup of the MI355X tractography environment.
+
+Host-side mirror of TrackToLearn/environments/env.py (``BaseEnv``).  It keeps
+the constructor signature ``(subject_data, split_id, env_dto)``, the env_dto
+keys of TrackToLearn/experiment/experiment.py:107-129, ``load_subject()``,
+``get_state_size/get_action_size/get_voxel_size/get_target_sh_order`` and the
+attributes the tracker and trainers read (``seeds``, ``affine_vox2rasmm``,
+``reference``, ``tracking_mask``, ``max_nb_steps``, ``step_size`` ...).
+
+All per-step arithmetic lives in the HIP library (libttl_hip.so, C ABI in
+include/ttl_hip.h).  There is no CPU path: a non-CUDA device or a missing
+library raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from tracktolearn_amd import _lib
+from tracktolearn_amd.datasets.utils import convert_length_mm2vox
+from tracktolearn_amd.environments.stopping_criteria import (
+    curvature_dot_threshold, mask_spline_coefficients)
+
+
+def random_seeds_from_mask(mask, seeds_count=1, rng=None):
+    """``seeds_count`` seeds per non-zero voxel, uniformly jittered inside the
+    voxel, in voxel space with voxel centres at integer coordinates.
+
+    Stand-in for ``dipy.tracking.utils.random_seeds_from_mask(mask, np.eye(4),
+    seeds_count=npv)`` called at TrackToLearn/environments/env.py:216-219
+    (dipy is absent here; seeds are *inputs* of the step path, so only their
+    distribution matters -- SURVEY 8c, "seeds": parity unpinned).
+    """
+    rng = rng if rng is not None else np.random.RandomState()
+    vox = np.argwhere(np.asarray(mask) > 0)
+    vox = np.repeat(vox, int(seeds_count), axis=0)
+    return vox + rng.uniform(size=vox.shape) - 0.5
+
+
+class BaseEnv(object):
+    """Abstract tracking environment (see TrackingEnvironment)."""
+
+    #: direction arithmetic forced to float64 by subclasses that add float64
+    #: noise to the action (NoisyTrackingEnvironment)
+    _force_f64_directions = False
+
+    def __init__(self, subject_data, split_id: str, env_dto: dict):
+        if type(subject_data) is str:
+            # TrackToLearn/environments/env.py:85-94 reads an HDF5 dataset
+            # through h5py + a torch DataLoader; h5py is absent from this
+            # image (SURVEY 8f.2 "input formats" is a next row).
+            raise NotImplementedError(
+                'HDF5 datasets need h5py, which this image lacks; pass the '
+                'tuple (input_volume, tracking_mask, seeding_mask, peaks, '
+                'reference) of MRIDataVolume objects instead')
+        self.subject_data = subject_data
+        self.split = split_id
+
+        self.normalize_obs = False
+        self.obs_rms = None
+        self._state_size = None
+
+        # env.py:105-138
+        self.n_dirs = env_dto['n_dirs']
+        self.theta = env_dto['theta']
+        self.npv = env_dto['npv']
+        self.binary_stopping_threshold = env_dto['binary_stopping_threshold']
+        self.step_size_mm = env_dto['step_size']
+        self.min_length_mm = env_dto['min_length']
+        self.max_length_mm = env_dto['max_length']
+        self.oracle_checkpoint = env_dto.get('oracle_checkpoint')
+        self.oracle_stopping_criterion = env_dto.get(
+            'oracle_stopping_criterion', False)
+        self.scoring_data = env_dto.get('scoring_data')
+        self.compute_reward = env_dto['compute_reward']
+        self.alignment_weighting = env_dto['alignment_weighting']
+        self.oracle_bonus = env_dto.get('oracle_bonus', 0)
+        self.rng = env_dto['rng']
+        self.device = torch.device(env_dto['device'])
+        self.target_sh_order = env_dto.get('target_sh_order')
+        #: offset added to coordinates before the SH gather (0: voxel i sits at
+        #: coordinate i); exposed because the third-party
+        #: interpolation it replaces could not be inspected offline
+        self.sh_coord_shift = float(env_dto.get('sh_coord_shift', 0.0))
+
+        if self.device.type != 'cuda':
+            raise RuntimeError(
+                'tracktolearn_amd environments run on an MI355X only '
+                f"(env_dto['device']={self.device}); there is no CPU fallback")
+        if self.oracle_stopping_criterion or (
+                self.compute_reward and self.oracle_bonus and
+                self.oracle_bonus > 0):
+            raise NotImplementedError(
+                'oracle reward / oracle stopping (SURVEY 8f.4) are not built '
+                'yet; run with oracle_bonus=0 and '
+                'oracle_stopping_criterion=False')
+
+        self._lib = _lib.load()
+        self._handle = None
+        self._n_max = 0
+        self.load_subject()
+
+    # ------------------------------------------------------------------ #
+    def load_subject(self):
+        """Per-subject setup, TrackToLearn/environments/env.py:143-281."""
+        (input_volume, tracking_mask, seeding_mask, peaks,
+         reference) = self.subject_data
+
+        self.affine_vox2rasmm = input_volume.affine_vox2rasmm
+        self.affine_rasmm2vox = np.linalg.inv(self.affine_vox2rasmm)
+        self.reference = reference
+
+        sh = np.ascontiguousarray(input_volume.data, dtype=np.float32)
+        if sh.ndim != 4:
+            raise ValueError('input volume must be (X, Y, Z, C)')
+        self.data_volume = torch.from_numpy(sh).to(self.device)
+        if self.target_sh_order is None:
+            # even, symmetric basis: C = (n+1)(n+2)/2
+            n_coefs = sh.shape[-1]
+            order = int(round((-3 + np.sqrt(1 + 8 * n_coefs)) / 2))
+            self.target_sh_order = order
+
+        self.tracking_mask = tracking_mask
+        self.peaks = peaks
+        mask_data = tracking_mask.data.astype(np.uint8)
+        self.seeding_data = seeding_mask.data.astype(np.uint8)
+
+        self.step_size = convert_length_mm2vox(
+            self.step_size_mm, self.affine_vox2rasmm)
+        self.min_length = self.min_length_mm
+        self.max_length = self.max_length_mm
+        self.max_nb_steps = int(self.max_length / self.step_size_mm)
+        self.min_nb_steps = int(self.min_length / self.step_size_mm)
+        self.add_neighborhood_vox = convert_length_mm2vox(
+            self.step_size_mm, self.affine_vox2rasmm)
+        r = np.float32(self.add_neighborhood_vox)
+        eye = torch.eye(3)
+        self.neighborhood_directions = torch.cat(
+            (torch.zeros((1, 3)), eye * float(r), -eye * float(r))
+        ).to(self.device)
+
+        self.seeds = random_seeds_from_mask(
+            self.seeding_data, seeds_count=self.npv, rng=self.rng)
+
+        # --- device-side volumes ------------------------------------- #
+        C_ = sh.shape[-1]
+        pitch = (C_ + 3) // 4 * 4
+        n_vox = int(np.prod(sh.shape[:3]))
+        self._sh_packed = torch.empty((n_vox, pitch), dtype=torch.float32,
+                                      device=self.device)
+        stream = self._stream()
+        _lib.check(self._lib.ttl_pack_sh_volume(
+            self.data_volume.data_ptr(), self._sh_packed.data_ptr(), n_vox,
+            C_, pitch, stream), 'ttl_pack_sh_volume')
+        self._n_coef, self._coef_pitch = C_, pitch
+        self._sh_dim = tuple(int(d) for d in sh.shape[:3])
+
+        # cubic B-spline coefficients: scipy on the host at load time, as
+        # BinaryStoppingCriterion.__init__ does (stopping_criteria.py:58-59)
+        coef = mask_spline_coefficients(mask_data)
+        self._mask_coef = torch.from_numpy(coef).to(self.device)
+        self._mask_dim = tuple(int(d) for d in coef.shape)
+
+        self._peaks_dev = None
+        self._peaks_dim = (0, 0, 0)
+        if self.compute_reward:
+            pk = np.ascontiguousarray(peaks.data, dtype=np.float32)
+            if pk.ndim != 4 or pk.shape[-1] != 15:
+                raise ValueError('peaks volume must be (X, Y, Z, 15)')
+            self._peaks_dev = torch.from_numpy(pk).to(self.device)
+            self._peaks_dim = tuple(int(d) for d in pk.shape[:3])
+
+        # float32 vs float64 direction arithmetic: whatever this host's numpy
+        # gives `float32_array * step_size`
+        promoted = (np.zeros(1, np.float32) * self.step_size).dtype
+        self._f64_directions = bool(self._force_f64_directions or
+                                    promoted == np.float64)
+        self._curv_dot_max, self._curv_enabled = \
+            curvature_dot_threshold(self.theta)
+
+        self._destroy_handle()
+        self._n_max = 0
+        self._state_width = 7 * C_ + 3 * int(self.n_dirs)
+
+    # ------------------------------------------------------------------ #
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _destroy_handle(self):
+        if getattr(self, '_handle', None):
+            self._lib.ttl_env_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy_handle()
+        except Exception:
+            pass
+
+    def _ensure_capacity(self, n):
+        """(Re)allocate the per-streamline buffers for ``n`` streamlines and
+        create the library handle over them (all buffers are torch tensors the
+        library borrows)."""
+        if self._handle and n <= self._n_max:
+            return
+        self._destroy_handle()
+        dev = self.device
+        n_max = int(n)
+        self._buf_streamlines = torch.empty(
+            (n_max, self.max_nb_steps + 1, 3), dtype=torch.float32, device=dev)
+        self._buf_flags = torch.zeros(n_max, dtype=torch.int32, device=dev)
+        self._buf_lengths = torch.zeros(n_max, dtype=torch.int32, device=dev)
+        self._buf_dones = torch.zeros(n_max, dtype=torch.uint8, device=dev)
+        self._buf_idx = torch.zeros((2, n_max), dtype=torch.int32, device=dev)
+        ws = int(self._lib.ttl_env_workspace_bytes(n_max))
+        self._buf_ws = torch.zeros(ws + 256, dtype=torch.uint8, device=dev)
+        ws_ptr = (self._buf_ws.data_ptr() + 255) // 256 * 256
+
+        d = _lib.EnvDesc()
+        d.abi_version = _lib.ABI_VERSION
+        d.mode = _lib.MODE_F64DIR if self._f64_directions else _lib.MODE_F32
+        d.sh_dim[:] = self._sh_dim
+        d.n_coef = self._n_coef
+        d.coef_pitch = self._coef_pitch
+        d.sh_packed = self._sh_packed.data_ptr()
+        d.sh_coord_shift = self.sh_coord_shift
+        d.mask_dim[:] = self._mask_dim
+        d.mask_coef = self._mask_coef.data_ptr()
+        d.mask_threshold = float(self.binary_stopping_threshold)
+        d.peaks_dim[:] = self._peaks_dim
+        d.peaks = self._peaks_dev.data_ptr() if self._peaks_dev is not None else None
+        d.compute_reward = 1 if self.compute_reward else 0
+        d.alignment_weighting = float(self.alignment_weighting)
+        d.n_dirs = int(self.n_dirs)
+        d.max_nb_steps = int(self.max_nb_steps)
+        d.step_size_vox = float(self.step_size)
+        d.neigh_radius_vox = float(np.float32(self.add_neighborhood_vox))
+        d.curvature_enabled = 1 if self._curv_enabled else 0
+        d.curv_dot_max = float(self._curv_dot_max)
+        d.n_max = n_max
+        d.streamlines = self._buf_streamlines.data_ptr()
+        d.flags = self._buf_flags.data_ptr()
+        d.lengths = self._buf_lengths.data_ptr()
+        d.dones = self._buf_dones.data_ptr()
+        d.idx_a = self._buf_idx[0].data_ptr()
+        d.idx_b = self._buf_idx[1].data_ptr()
+        d.workspace = ws_ptr
+        d.workspace_bytes = ws
+        handle = C.c_void_p()
+        _lib.check(self._lib.ttl_env_create(C.byref(d), C.byref(handle)),
+                   'ttl_env_create')
+        self._handle = handle
+        self._n_max = n_max
+        self._host_counts = torch.zeros(2, dtype=torch.int32).pin_memory()
+
+    # ------------------------------------------------------------------ #
+    @classmethod
+    def from_dataset(cls, env_dto: dict, split: str):
+        """env.py:284-309."""
+        return cls(env_dto['dataset_file'], split, env_dto)
+
+    @classmethod
+    def from_files(cls, env_dto: dict):
+        """env.py:311-347 -- needs a NIfTI reader (nibabel is absent; SURVEY
+        8f.2 is a next row)."""
+        raise NotImplementedError(
+            'from_files needs the NIfTI reader (SURVEY 8f.2, not built yet)')
+
+    def get_state_size(self):
+        """env.py:451-463."""
+        example_state = self.reset(0, 1)
+        self._state_size = example_state.shape[1]
+        return self._state_size
+
+    def get_action_size(self):
+        return 3
+
+    def get_target_sh_order(self):
+        return self.target_sh_order
+
+    def get_voxel_size(self):
+        """env.py:478-491."""
+        diag = np.diagonal(self.affine_vox2rasmm)[:3]
+        return np.mean(np.abs(diag))

@@ -1,0 +1,43 @@
+"""NoisyTrackingEnvironment: gaussian noise on the action, float64 direction
+arithmetic.
+
+Host-side mirror of TrackToLearn/environments/noisy_tracking_env.py.  The
+reference adds ``rng.normal(0, noise, size)`` (float64 -- also when noise is
+0) to the float32 action before ``TrackingEnvironment.step``, so normalise /
+scale / position update run in float64; the HIP library does the
+same in TTL_MODE_F64DIR.
+"""
+import numpy as np
+import torch
+
+from tracktolearn_amd.environments.tracking_env import TrackingEnvironment
+
+
+class NoisyTrackingEnvironment(TrackingEnvironment):
+
+    _force_f64_directions = True
+
+    def __init__(self, dataset_file, split_id: str, env_dto: dict):
+        self.noise = env_dto['noise']
+        self.fa_map = None
+        if env_dto.get('fa_map'):
+            # noisy_tracking_env.py:65-72 scales the noise by (1 - FA) but its
+            # broadcast (N,3)+(N,) only works for N == 3;
+            # the branch is unreachable from ttl_track.py ('fa_map_file' key).
+            raise NotImplementedError('FA-scaled noise is not supported')
+        #: draw the noise with torch on the device instead of env_dto['rng'] on
+        #: the host (not bit-compatible with the reference's RNG stream)
+        self.device_noise = bool(env_dto.get('device_noise', False))
+        self.max_action = 1.
+        super().__init__(dataset_file, split_id, env_dto)
+
+    def _noise_for(self, actions):
+        """noisy_tracking_env.py:73-77.  sigma == 0 adds +0.0 (done inside the
+        kernel) and, unlike the reference, does not advance ``rng``."""
+        if not self.noise > 0.:
+            return None
+        if self.device_noise:
+            return torch.randn(actions.shape, dtype=torch.float64,
+                               device=self.device) * float(self.noise)
+        noise = self.rng.normal(0., self.noise, size=tuple(actions.shape))
+        return torch.from_numpy(np.ascontiguousarray(noise)).to(self.device)

@@ -1,0 +1,288 @@
+"""TrackingEnvironment: reset / nreset / step / harvest / get_streamlines on
+the MI355X.
+
+Host-side mirror of TrackToLearn/environments/tracking_env.py.  Method names,
+arguments and return shapes follow the reference; the arithmetic runs in
+libttl_hip.so:
+
+  reference call                      C ABI entry point (include/ttl_hip.h)
+  reset / nreset   (:91-133/:47-89)   ttl_env_reset
+  step             (:135-221)         ttl_env_step
+  harvest          (:223-245)         ttl_env_harvest
+  get_streamlines  (:247-294)         device-side ragged pack (torch) + D2H
+
+Two flavours of the step loop are offered:
+
+  * ``step()`` / ``harvest()``: the reference's contract.  ``state`` is a
+    float32 ``torch.Tensor`` on the GPU; ``reward`` (float64) and ``dones``
+    (bool) are host numpy arrays as in the reference, which costs one small
+    device->host copy + stream sync per step.
+  * ``step_device()``: everything stays on the device (torch tensors), state
+    rows are written survivors-first so that ``harvest()`` returns a view and
+    copies nothing.  ``RLAlgorithm.validation_episode``-style loops that only
+    use the harvested state get identical results from either flavour.
+"""
+import numpy as np
+import torch
+
+from tracktolearn_amd import _lib
+from tracktolearn_amd.environments.env import BaseEnv
+from tracktolearn_amd.environments.stopping_criteria import (
+    StoppingFlags, is_flag_set)
+from tracktolearn_amd.tractogram import Tractogram
+
+
+class _StepInfo(dict):
+    """``info`` dict of ``step``; 'continue_idx' is downloaded on first use
+    (the reference puts the host index array there, tracking_env.py:220)."""
+
+    def __init__(self, env, n_active, reward_info):
+        super().__init__(reward_info=reward_info)
+        self._env, self._n = env, n_active
+        self._idx_dev = env._idx_view(n_active)
+
+    def __missing__(self, key):
+        if key == 'continue_idx':
+            val = self._idx_dev.to('cpu').numpy().astype(np.int64)
+            self[key] = val
+            return val
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == 'continue_idx' or super().__contains__(key)
+
+
+class TrackingEnvironment(BaseEnv):
+    """Tracking environment; also the "tracker" (see the reference class)."""
+
+    # ------------------------------------------------------------------ #
+    def _idx_view(self, n):
+        """Device view (int32) of the current continue_idx."""
+        return self._buf_idx[self._cur][:n]
+
+    def _start(self, initial_points):
+        n = int(initial_points.shape[0])
+        if n < 1:
+            raise ValueError('need at least one seed')
+        self.initial_points = initial_points
+        self._ensure_capacity(n)
+        seeds32 = torch.from_numpy(
+            np.ascontiguousarray(initial_points, dtype=np.float32)
+        ).to(self.device)
+        state = torch.empty((n, self._state_width), dtype=torch.float32,
+                            device=self.device)
+        _lib.check(self._lib.ttl_env_reset(
+            self._handle, seeds32.data_ptr(), n, state.data_ptr(),
+            self._state_width, self._stream()), 'ttl_env_reset')
+        self._n_total = n
+        self._n_active = n
+        self._cur = 0
+        self.length = 1
+        self._pending = None
+        self.not_stopping = None
+        return state
+
+    def nreset(self, n_seeds: int):
+        """N random seeds among all seeds (tracking_env.py:47-89; global
+        numpy RNG, as the reference)."""
+        replace = n_seeds > len(self.seeds)
+        picks = np.random.choice(
+            np.arange(len(self.seeds)), size=n_seeds, replace=replace)
+        return self._start(self.seeds[picks])
+
+    def reset(self, start: int, end: int):
+        """A given batch of seeds (tracking_env.py:91-133)."""
+        return self._start(self.seeds[start:end])
+
+    # ------------------------------------------------------------------ #
+    def _actions_to_device(self, actions):
+        if isinstance(actions, torch.Tensor):
+            a = actions.to(device=self.device, dtype=torch.float32)
+        else:
+            a = torch.from_numpy(
+                np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+        a = a.contiguous()
+        if a.shape != (self._n_active, 3):
+            raise ValueError(
+                f'actions must be ({self._n_active}, 3), got {tuple(a.shape)}')
+        return a
+
+    def _noise_for(self, actions):
+        """float64 noise added to the action before normalisation, or None.
+        Only NoisyTrackingEnvironment returns something."""
+        return None
+
+    def _launch_step(self, actions, order):
+        if self._pending is not None:
+            raise RuntimeError('harvest() the previous step first')
+        n = self._n_active
+        if n < 1:
+            raise RuntimeError('no active streamline left; reset first')
+        a = self._actions_to_device(actions)
+        noise = self._noise_for(a)
+        state = torch.empty((n, self._state_width), dtype=torch.float32,
+                            device=self.device)
+        done = torch.empty(n, dtype=torch.uint8, device=self.device)
+        reward = None
+        if self.compute_reward:
+            reward = torch.empty(n, dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.ttl_env_step(
+            self._handle, a.data_ptr(),
+            noise.data_ptr() if noise is not None else None, n, order,
+            state.data_ptr(), self._state_width,
+            reward.data_ptr() if reward is not None else None,
+            done.data_ptr(), self._stream()), 'ttl_env_step')
+        self.length += 1
+        self._pending = dict(order=order, state=state, n=n, done=done,
+                             keep=(a, noise))
+        return state, reward, done
+
+    def step(self, actions):
+        """Apply actions, grow every active streamline by one step, test the
+        stopping criteria, compute the reward and the new state
+        (tracking_env.py:135-221).
+
+        Returns ``(state, reward, dones, info)``: state rows for all currently
+        active streamlines (incl. the ones that just stopped) as a float32 GPU
+        tensor in continue_idx order; ``reward`` float64 numpy (zeros of size
+        N_total when rewards are off, tracking_env.py:204); ``dones`` bool
+        numpy; ``info`` = {'continue_idx', 'reward_info'}.
+        """
+        state, reward, done = self._launch_step(actions, _lib.ORDER_ACTIVE)
+        dones = done.to('cpu').numpy().astype(bool)      # syncs the stream
+        self._pending['dones_host'] = dones
+        reward_info = {}
+        if reward is not None:
+            reward_np = reward.to('cpu').numpy()
+            # reward.py:73-75: mean of each weighted factor
+            reward_info = {'peaks_reward': np.mean(reward_np),
+                           'oracle_reward': np.float64(0.0)}
+        else:
+            reward_np = np.zeros(self._n_total)
+        info = _StepInfo(self, self._pending['n'], reward_info)
+        return state, reward_np, dones, info
+
+    def step_device(self, actions):
+        """Device-resident step: no host copy, no sync.  ``state`` rows are
+        written survivors first (stable), then the streamlines that stopped in
+        this step (stable); ``info['row_dest'][i]`` is the state row of active
+        row ``i``.  ``reward`` (float64 or None) and ``dones`` (uint8) are GPU
+        tensors in active-row order.  ``harvest()`` afterwards returns the
+        leading rows of ``state`` without copying."""
+        state, reward, done = self._launch_step(actions, _lib.ORDER_PARTITION)
+        n = self._pending['n']
+        info = {'row_dest': self._row_dest_view(n), 'reward_info': {}}
+        return state, reward, done, info
+
+    def _row_dest_view(self, n):
+        from ctypes import byref, c_int32, c_void_p
+        idx_p, dest_p, length = c_void_p(), c_void_p(), c_int32()
+        _lib.check(self._lib.ttl_env_view(
+            self._handle, byref(idx_p), byref(dest_p), byref(length)),
+            'ttl_env_view')
+        off = dest_p.value - self._buf_ws.data_ptr()
+        return self._buf_ws[off:off + 4 * n].view(torch.int32)
+
+    def harvest(self):
+        """Drop the streamlines that stopped in the last step
+        (tracking_env.py:223-245).  Returns ``(state, not_stopping)``: the
+        state rows of the streamlines still being tracked, and the boolean
+        mask over the previous active rows: host numpy after ``step()`` (as
+        the reference), a GPU bool tensor after ``step_device()``."""
+        if self._pending is None:
+            raise RuntimeError('no step to harvest')
+        pend = self._pending
+        n = pend['n']
+        order = pend['order']
+        state_in = pend['state']
+        out = None
+        if order == _lib.ORDER_ACTIVE:
+            out = torch.empty_like(state_in)
+        _lib.check(self._lib.ttl_env_harvest(
+            self._handle, state_in.data_ptr(),
+            out.data_ptr() if out is not None else None, self._state_width,
+            self._host_counts.data_ptr(), self._stream()), 'ttl_env_harvest')
+        torch.cuda.current_stream(self.device).synchronize()
+        n_cont = int(self._host_counts[0])
+        if order == _lib.ORDER_ACTIVE:
+            new_state = out[:n_cont]
+        else:
+            new_state = state_in[:n_cont]
+        if 'dones_host' in pend:
+            self.not_stopping = np.logical_not(pend['dones_host'])
+        else:
+            self.not_stopping = pend['done'] == 0
+        self._cur ^= 1
+        self._n_active = n_cont
+        self._pending = None
+        return new_state, self.not_stopping
+
+    def _compute_stopping_flags(self, streamlines, stopping_criteria=None):
+        """Which of the given streamlines should stop, and why
+        (TrackToLearn/environments/env.py:567-603) -- evaluated on the GPU for
+        arbitrary ``streamlines`` (N, L, 3); the env state is not touched.
+        Returns ``(should_stop bool (N,), flags int (N,))`` on the host."""
+        pts = np.ascontiguousarray(streamlines, dtype=np.float32)
+        n, n_points = pts.shape[0], pts.shape[1]
+        tail = np.zeros((n, 3, 3), dtype=np.float32)
+        k = min(3, n_points)
+        tail[:, 3 - k:] = pts[:, n_points - k:]
+        self._ensure_capacity(1)
+        tail_dev = torch.from_numpy(tail).to(self.device)
+        out = torch.empty(n, dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.ttl_env_stopping_flags(
+            self._handle, tail_dev.data_ptr(), n, n_points, out.data_ptr(),
+            self._stream()), 'ttl_env_stopping_flags')
+        flags = out.to('cpu').numpy().astype(int)
+        return flags != 0, flags
+
+    def _is_stopping(self, streamlines):
+        """tracking_env.py:22-45."""
+        return self._compute_stopping_flags(streamlines)
+
+    # ------------------------------------------------------------------ #
+    # host views of the per-streamline state (reference attribute names)
+    @property
+    def continue_idx(self):
+        return self._idx_view(self._n_active).to('cpu').numpy().astype(np.int64)
+
+    @property
+    def flags(self):
+        return self._buf_flags[:self._n_total].to('cpu').numpy().astype(np.int64)
+
+    @property
+    def lengths(self):
+        return self._buf_lengths[:self._n_total].to('cpu').numpy()
+
+    @property
+    def dones(self):
+        return self._buf_dones[:self._n_total].to('cpu').numpy().astype(bool)
+
+    @property
+    def streamlines(self):
+        """(N, max_nb_steps + 1, 3) float32 history, downloaded."""
+        return self._buf_streamlines[:self._n_total].to('cpu').numpy()
+
+    def get_streamlines(self):
+        """Tracked streamlines in voxel space (tracking_env.py:247-294): each
+        streamline's ``lengths[i]`` points, minus the last one if it raised the
+        CURVATURE or MASK flag; ``data_per_streamline`` = seeds and flags.  The
+        ragged list is packed on the device and downloaded once."""
+        n = self._n_total
+        flags_dev = self._buf_flags[:n]
+        lengths_dev = self._buf_lengths[:n].to(torch.int64)
+        cut = (StoppingFlags.STOPPING_CURVATURE.value |
+               StoppingFlags.STOPPING_MASK.value)
+        keep_len = lengths_dev - ((flags_dev & cut) != 0).to(torch.int64)
+        hist = self._buf_streamlines[:n]
+        steps = torch.arange(hist.shape[1], device=self.device)
+        valid = steps[None, :] < keep_len[:, None]
+        points = hist[valid].to('cpu').numpy()
+        keep_len_np = keep_len.to('cpu').numpy()
+        offsets = np.concatenate(([0], np.cumsum(keep_len_np)))
+        stopped_streamlines = [points[offsets[i]:offsets[i + 1]]
+                               for i in range(n)]
+        return Tractogram(
+            streamlines=stopped_streamlines,
+            data_per_streamline={'seeds': self.initial_points,
+                                 'flags': self.flags})
