@@ -40,11 +40,18 @@ extern "C" {
 #define TTL_ERR_HIP (-2)     /* a HIP runtime call failed                    */
 #define TTL_ERR_STATE (-3)   /* call order violated (e.g. step before reset) */
 
-/* Direction arithmetic: TTL/environments/env.py:493-502 runs in
- * float32 for the training env and in float64 for NoisyTrackingEnvironment
- * (TTL/environments/noisy_tracking_env.py:65-77). */
+/* Direction arithmetic, TTL/environments/env.py:493-502:
+ *   F32      normalise, scale and add in float32 (training env, float32
+ *            affine; also any affine under numpy 1.x).
+ *   F64DIR   NoisyTrackingEnvironment (noisy_tracking_env.py:65-77): float64
+ *            noise is added first, so normalise/scale/add run in float64 and
+ *            the new point is float32(float64(p) + d).
+ *   F32NORM  float32 normalise, float64 scale/add: what numpy >= 2 computes
+ *            for the plain TrackingEnvironment when step_size is np.float64
+ *            (float64 affine). */
 #define TTL_MODE_F32 0
 #define TTL_MODE_F64DIR 1
+#define TTL_MODE_F32NORM 2
 
 /* StoppingFlags, TTL/environments/stopping_criteria.py:10-20 */
 #define TTL_FLAG_MASK 1

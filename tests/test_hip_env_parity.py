@@ -129,7 +129,8 @@ def test_reference_trace_device_loop(name):
         if bool(z['reward']):
             assert _close(rew.cpu().numpy(), z[f'reward_{s}'])
         hstate, not_stopping = env.harvest()
-        assert hstate.data_ptr() == nstate.data_ptr()      # a view, no copy
+        if hstate.shape[0]:
+            assert hstate.data_ptr() == nstate.data_ptr()  # a view, no copy
         assert hstate.shape[0] == int(z[f'harvest_rows_{s}'])
         assert np.array_equal(not_stopping.cpu().numpy(), ~z[f'dones_{s}'])
         assert np.array_equal(env.continue_idx, z[f'new_continue_idx_{s}'])

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 ABI_VERSION = 1
 MODE_F32 = 0
 MODE_F64DIR = 1
+MODE_F32NORM = 2
 ORDER_ACTIVE = 0
 ORDER_PARTITION = 1
 

@@ -155,6 +155,18 @@ __device__ bool outside_mask(const EnvParams &P, float px, float py, float pz) {
     return t < P.mask_thr;
 }
 
+// tracking_env.py:165-178: at the first step all criteria run on the 2-point
+// trial streamline; only LENGTH (2 >= max_nb_steps) and MASK can fire there.
+// NOTE (ROCm 7.2 hipcc): written as `a || outside_mask(..)` followed by
+// `if (flip) d = -d`, the divergent arm lost its body in the ISA (the
+// direction was never negated).  Keep the non-short-circuit form below and
+// apply the flip with selects; tests/test_hip_env_parity.py covers it.
+__device__ __forceinline__ bool first_step_flips(const EnvParams &P, float tx,
+                                                 float ty, float tz) {
+    const bool out = outside_mask(P, tx, ty, tz);
+    return out | (2 >= P.max_nb_steps);
+}
+
 // normalize_vectors on one float32 3-vector: v / sqrt((x*x + y*y) + z*z)
 __device__ __forceinline__ void unit3(float x, float y, float z, float &ox,
                                       float &oy, float &oz) {
@@ -228,46 +240,51 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
             float dy = (ay / s) * P.step32;
             float dz = (az / s) * P.step32;
             if (L == 1) {
+                // first step: a trial step that would stop is reversed
                 const float tx = p1x + dx, ty = p1y + dy, tz = p1z + dz;
-                const bool flip =
-                    (2 >= P.max_nb_steps) || outside_mask(P, tx, ty, tz);
-                if (flip) {
-                    dx = -dx;
-                    dy = -dy;
-                    dz = -dz;
-                }
+                const bool flip = first_step_flips(P, tx, ty, tz);
+                dx = flip ? -dx : dx;
+                dy = flip ? -dy : dy;
+                dz = flip ? -dz : dz;
             }
             p2x = p1x + dx;
             p2y = p1y + dy;
             p2z = p1z + dz;
         } else {
-            // float64: (actions + noise) -> normalise -> * step_size; the new
-            // point is float32(float64(p) + d)
-            double a0 = (double)ax, a1 = (double)ay, a2 = (double)az;
-            if (noise) {
-                a0 = a0 + noise[(size_t)i * 3 + 0];
-                a1 = a1 + noise[(size_t)i * 3 + 1];
-                a2 = a2 + noise[(size_t)i * 3 + 2];
+            // float64 directions; the new point is float32(float64(p) + d)
+            double dx, dy, dz;
+            if (MODE == TTL_MODE_F32NORM) {
+                // float32 normalise, then float32_array * np.float64 step
+                // (plain TrackingEnvironment with a float64 affine, numpy >= 2)
+                const float s = sqrtf((ax * ax + ay * ay) + az * az);
+                dx = (double)(ax / s) * P.step64;
+                dy = (double)(ay / s) * P.step64;
+                dz = (double)(az / s) * P.step64;
             } else {
-                a0 = a0 + 0.0;
-                a1 = a1 + 0.0;
-                a2 = a2 + 0.0;
+                // (actions + noise) in float64 -> normalise -> * step_size
+                double a0 = (double)ax, a1 = (double)ay, a2 = (double)az;
+                if (noise) {
+                    a0 = a0 + noise[(size_t)i * 3 + 0];
+                    a1 = a1 + noise[(size_t)i * 3 + 1];
+                    a2 = a2 + noise[(size_t)i * 3 + 2];
+                } else {
+                    a0 = a0 + 0.0;
+                    a1 = a1 + 0.0;
+                    a2 = a2 + 0.0;
+                }
+                const double s = sqrt((a0 * a0 + a1 * a1) + a2 * a2);
+                dx = (a0 / s) * P.step64;
+                dy = (a1 / s) * P.step64;
+                dz = (a2 / s) * P.step64;
             }
-            const double s = sqrt((a0 * a0 + a1 * a1) + a2 * a2);
-            double dx = (a0 / s) * P.step64;
-            double dy = (a1 / s) * P.step64;
-            double dz = (a2 / s) * P.step64;
             if (L == 1) {
                 const float tx = (float)((double)p1x + dx);
                 const float ty = (float)((double)p1y + dy);
                 const float tz = (float)((double)p1z + dz);
-                const bool flip =
-                    (2 >= P.max_nb_steps) || outside_mask(P, tx, ty, tz);
-                if (flip) {
-                    dx = -dx;
-                    dy = -dy;
-                    dz = -dz;
-                }
+                const bool flip = first_step_flips(P, tx, ty, tz);
+                dx = flip ? -dx : dx;
+                dy = flip ? -dy : dy;
+                dz = flip ? -dz : dz;
             }
             p2x = (float)((double)p1x + dx);
             p2y = (float)((double)p1y + dy);
@@ -633,7 +650,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     if (d.abi_version != TTL_ABI_VERSION)
         return fail(TTL_ERR_INVALID, "ttl_env_create: abi_version %u != %u",
                     d.abi_version, TTL_ABI_VERSION);
-    if (d.mode != TTL_MODE_F32 && d.mode != TTL_MODE_F64DIR)
+    if (d.mode != TTL_MODE_F32 && d.mode != TTL_MODE_F64DIR &&
+        d.mode != TTL_MODE_F32NORM)
         return fail(TTL_ERR_INVALID, "ttl_env_create: bad mode %d", d.mode);
     for (int a = 0; a < 3; ++a) {
         if (d.sh_dim[a] <= 0 || d.mask_dim[a] <= 0)
@@ -779,14 +797,13 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
     int *idx_next = env->cur ? d.idx_a : d.idx_b;
     const int L = env->length;
     const int nb = (n_active + BLOCK - 1) / BLOCK;
-    if (d.mode == TTL_MODE_F32)
-        hipLaunchKernelGGL((k_advance<TTL_MODE_F32>), dim3(nb), dim3(BLOCK), 0, s,
-                           env->P, idx, actions, noise, n_active, L, reward_out,
-                           done_out);
-    else
-        hipLaunchKernelGGL((k_advance<TTL_MODE_F64DIR>), dim3(nb), dim3(BLOCK), 0,
-                           s, env->P, idx, actions, noise, n_active, L,
-                           reward_out, done_out);
+#define TTL_LAUNCH_ADVANCE(M)                                                  \
+    hipLaunchKernelGGL((k_advance<M>), dim3(nb), dim3(BLOCK), 0, s, env->P, idx, \
+                       actions, noise, n_active, L, reward_out, done_out)
+    if (d.mode == TTL_MODE_F32) TTL_LAUNCH_ADVANCE(TTL_MODE_F32);
+    else if (d.mode == TTL_MODE_F64DIR) TTL_LAUNCH_ADVANCE(TTL_MODE_F64DIR);
+    else TTL_LAUNCH_ADVANCE(TTL_MODE_F32NORM);
+#undef TTL_LAUNCH_ADVANCE
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
                        n_active, nb, order);

@@ -173,8 +173,12 @@ class BaseEnv(object):
         # float32 vs float64 direction arithmetic: whatever this host's numpy
         # gives `float32_array * step_size`
         promoted = (np.zeros(1, np.float32) * self.step_size).dtype
-        self._f64_directions = bool(self._force_f64_directions or
-                                    promoted == np.float64)
+        if self._force_f64_directions:
+            self._mode = _lib.MODE_F64DIR
+        elif promoted == np.float64:
+            self._mode = _lib.MODE_F32NORM
+        else:
+            self._mode = _lib.MODE_F32
         self._curv_dot_max, self._curv_enabled = \
             curvature_dot_threshold(self.theta)
 
@@ -218,7 +222,7 @@ class BaseEnv(object):
 
         d = _lib.EnvDesc()
         d.abi_version = _lib.ABI_VERSION
-        d.mode = _lib.MODE_F64DIR if self._f64_directions else _lib.MODE_F32
+        d.mode = self._mode
         d.sh_dim[:] = self._sh_dim
         d.n_coef = self._n_coef
         d.coef_pitch = self._coef_pitch
