@@ -178,6 +178,26 @@ int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
 int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
                  const int32_t **row_dest, int32_t *length);
 
+/* Measurement support (bench.py): while profiling is on, every kernel launched
+ * by ttl_env_step() is bracketed by HIP events on the caller's stream.
+ * ttl_env_profile_end() synchronises those events and returns, per kernel
+ * class {0: advance, 1: prefix, 2: state gather}, the summed duration in ms
+ * and the number of launches, then switches profiling off. */
+int ttl_env_profile_begin(ttl_env *env, int32_t max_launches);
+int ttl_env_profile_end(ttl_env *env, double *total_ms /*[3]*/,
+                        int32_t *n_launches /*[3]*/);
+
+/* Scripted, policy-free actions for "env.step only" runs (stands in
+ * for agent.select_action, TTL/algorithms/rl.py:91): step 0 -> a random
+ * vector; later -> unit(previous segment) + wobble * noise, the previous
+ * segment being state[i][dir_offset .. dir_offset+2] (dir_offset = 7*C).  The
+ * noise is a counter-based hash of (seed, step, continue_idx[i], component),
+ * reproduced bit for bit by oracle/scripted_policy.py. */
+int ttl_scripted_actions(const float *state, int64_t state_pitch,
+                         int32_t dir_offset, const int32_t *continue_idx,
+                         int32_t n, uint32_t seed, uint32_t step, float wobble,
+                         float *actions_out, void *hip_stream);
+
 const char *ttl_last_error(void);
 uint32_t ttl_abi_version(void);
 

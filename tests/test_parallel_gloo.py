@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests (CPU) of the sharding helpers and of the ragged
+all-gather that collates finished tracts."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tracktolearn_amd import parallel
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 9, 262144, 1048576 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d
+
+
+def _fake_env(rank):
+    """A host-tensor stand-in for the env buffers: rank r owns 3 + 2r
+    streamlines of up to 6 points."""
+    rng = np.random.RandomState(10 + rank)
+    n, T = 3 + 2 * rank, 6
+    hist = torch.from_numpy(rng.standard_normal((n, T, 3)).astype(np.float32))
+    lengths = torch.from_numpy(rng.randint(1, T + 1, n).astype(np.int32))
+    flags = torch.from_numpy(rng.choice([1, 2, 4, 5], n).astype(np.int32))
+    return SimpleNamespace(_n_total=n, _buf_streamlines=hist,
+                           _buf_lengths=lengths, _buf_flags=flags,
+                           initial_points=rng.uniform(size=(n, 3)))
+
+
+def _expected():
+    lines, flags = [], []
+    for r in range(2):
+        e = _fake_env(r)
+        for i in range(e._n_total):
+            k = int(e._buf_lengths[i]) - (1 if int(e._buf_flags[i]) & 5 else 0)
+            lines.append(e._buf_streamlines[i, :k].numpy())
+            flags.append(int(e._buf_flags[i]))
+    return lines, flags
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        env = _fake_env(rank)
+        pieces = parallel.all_gather_ragged(env._buf_lengths)
+        assert [p.shape[0] for p in pieces] == [3, 5]
+        lengths, flags = parallel.all_gather_tract_index(env)
+        tg = parallel.all_gather_tractogram(env)
+        lines, want_flags = _expected()
+        assert len(tg) == 8 and lengths.shape[0] == 8
+        assert list(tg.data_per_streamline['flags']) == want_flags
+        assert tg.data_per_streamline['seeds'].shape == (8, 3)
+        for got, want in zip(tg.streamlines, lines):
+            assert np.array_equal(got, want)
+        q.put((rank, 'ok'))
+    except Exception as exc:          # pragma: no cover
+        q.put((rank, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_all_gather_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, 'ok'), (1, 'ok')], results

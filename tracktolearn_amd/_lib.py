@@ -75,6 +75,13 @@ SYMBOLS = {
                                          C.c_int32, C.c_void_p, C.c_void_p]),
     'ttl_env_view': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    'ttl_env_profile_begin': (C.c_int, [C.c_void_p, C.c_int32]),
+    'ttl_env_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_int32)]),
+    'ttl_scripted_actions': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_void_p, C.c_int32, C.c_uint32,
+                                       C.c_uint32, C.c_float, C.c_void_p,
+                                       C.c_void_p]),
     'ttl_last_error': (C.c_char_p, []),
     'ttl_abi_version': (C.c_uint32, []),
 }

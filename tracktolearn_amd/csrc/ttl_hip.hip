@@ -594,6 +594,61 @@ __global__ __launch_bounds__(BLOCK) void k_pack_sh(const float *__restrict__ src
     dst[t] = (c < C) ? src[v * C + c] : 0.0f;
 }
 
+// ---------------------------------------------------------------------------
+// Scripted, policy-free actions for "env.step only" measurements and tests
+// (SURVEY 8d): step 0 -> a random direction; later steps -> unit(previous
+// segment, read from the state row) + wobble * noise.  The noise is a
+// counter-based hash of (seed, step, global streamline id, component), so the
+// CPU twin (oracle/scripted_policy.py) produces the same bits regardless of
+// compaction.  Noise = centred sum of 4 uniforms * sqrt(3) (unit variance).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ float scripted_noise(unsigned seed, unsigned step,
+                                                unsigned gid, unsigned comp) {
+    const unsigned base = mix32(seed * 0x9E3779B1u + step) ^
+                          mix32(gid * 0x27D4EB2Fu + comp * 0x165667B1u + 0x1234567u);
+    float acc = 0.0f;
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) {
+        const unsigned h = mix32(base + k * 0x9E3779B9u);
+        acc = acc + (float)(h >> 8) * 5.9604644775390625e-08f;  // 2^-24, exact
+    }
+    return (acc - 2.0f) * 1.7320508075688772f;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scripted_actions(
+    const float *__restrict__ state, long long pitch, int dir_offset,
+    const int *__restrict__ idx, int n, unsigned seed, unsigned step,
+    float wobble, float *__restrict__ actions) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned gid = (unsigned)idx[i];
+    const float n0 = scripted_noise(seed, step, gid, 0);
+    const float n1 = scripted_noise(seed, step, gid, 1);
+    const float n2 = scripted_noise(seed, step, gid, 2);
+    float a0 = n0, a1 = n1, a2 = n2;
+    if (step > 0) {
+        const float *row = state + (size_t)i * (size_t)pitch + dir_offset;
+        const float px = row[0], py = row[1], pz = row[2];
+        float s = sqrtf((px * px + py * py) + pz * pz);
+        if (!(s > 0.0f)) s = 1.0f;
+        a0 = px / s + wobble * n0;
+        a1 = py / s + wobble * n1;
+        a2 = pz / s + wobble * n2;
+    }
+    actions[(size_t)i * 3 + 0] = a0;
+    actions[(size_t)i * 3 + 1] = a1;
+    actions[(size_t)i * 3 + 2] = a2;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -607,7 +662,18 @@ struct ttl_env {
     int stepped;     // a step is waiting for its harvest
     int last_order;
     int last_n;      // n_active of the pending step
+    // optional per-kernel timing with HIP events on the caller's stream
+    int prof_on;
+    int prof_cap;     // event pairs available per kernel class
+    int prof_n[3];    // launches recorded: advance, prefix, state
+    hipEvent_t *prof_ev[3];  // [2 * prof_cap] start/stop pairs
 };
+
+static void prof_mark(ttl_env *e, int which, int stop, hipStream_t s) {
+    if (!e->prof_on || e->prof_n[which] >= e->prof_cap) return;
+    (void)hipEventRecord(e->prof_ev[which][2 * e->prof_n[which] + stop], s);
+    if (stop) e->prof_n[which]++;
+}
 
 extern "C" {
 
@@ -723,11 +789,81 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->stepped = 0;
     e->last_order = TTL_ORDER_ACTIVE;
     e->last_n = 0;
+    e->prof_on = 0;
+    e->prof_cap = 0;
+    for (int k = 0; k < 3; ++k) {
+        e->prof_n[k] = 0;
+        e->prof_ev[k] = nullptr;
+    }
     *out = e;
     return TTL_OK;
 }
 
-void ttl_env_destroy(ttl_env *env) { delete env; }
+static void prof_free(ttl_env *env) {
+    for (int k = 0; k < 3; ++k) {
+        if (env->prof_ev[k]) {
+            for (int j = 0; j < 2 * env->prof_cap; ++j) (void)hipEventDestroy(env->prof_ev[k][j]);
+            delete[] env->prof_ev[k];
+            env->prof_ev[k] = nullptr;
+        }
+        env->prof_n[k] = 0;
+    }
+    env->prof_cap = 0;
+    env->prof_on = 0;
+}
+
+void ttl_env_destroy(ttl_env *env) {
+    if (!env) return;
+    prof_free(env);
+    delete env;
+}
+
+int ttl_env_profile_begin(ttl_env *env, int32_t max_launches) {
+    if (!env || max_launches < 1 || max_launches > (1 << 20))
+        return fail(TTL_ERR_INVALID, "ttl_env_profile_begin: bad arguments");
+    prof_free(env);
+    for (int k = 0; k < 3; ++k) {
+        env->prof_ev[k] = new (std::nothrow) hipEvent_t[2 * (size_t)max_launches];
+        if (!env->prof_ev[k]) return fail(TTL_ERR_INVALID, "ttl_env_profile_begin: out of host memory");
+        for (int j = 0; j < 2 * max_launches; ++j) HIP_TRY(hipEventCreate(&env->prof_ev[k][j]));
+    }
+    env->prof_cap = max_launches;
+    env->prof_on = 1;
+    return TTL_OK;
+}
+
+int ttl_env_profile_end(ttl_env *env, double *total_ms, int32_t *n_launches) {
+    if (!env || !total_ms || !n_launches)
+        return fail(TTL_ERR_INVALID, "ttl_env_profile_end: null argument");
+    if (!env->prof_cap) return fail(TTL_ERR_STATE, "ttl_env_profile_end: profiling is off");
+    for (int k = 0; k < 3; ++k) {
+        double acc = 0.0;
+        for (int j = 0; j < env->prof_n[k]; ++j) {
+            float ms = 0.f;
+            HIP_TRY(hipEventSynchronize(env->prof_ev[k][2 * j + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, env->prof_ev[k][2 * j], env->prof_ev[k][2 * j + 1]));
+            acc += ms;
+        }
+        total_ms[k] = acc;
+        n_launches[k] = env->prof_n[k];
+    }
+    prof_free(env);
+    return TTL_OK;
+}
+
+int ttl_scripted_actions(const float *state, int64_t state_pitch, int32_t dir_offset,
+                         const int32_t *continue_idx, int32_t n, uint32_t seed,
+                         uint32_t step, float wobble, float *actions_out,
+                         void *hip_stream) {
+    if (!state || !continue_idx || !actions_out || n < 1 || dir_offset < 0 ||
+        state_pitch < dir_offset + 3)
+        return fail(TTL_ERR_INVALID, "ttl_scripted_actions: bad arguments");
+    hipLaunchKernelGGL(k_scripted_actions, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
+                       (hipStream_t)hip_stream, state, (long long)state_pitch,
+                       dir_offset, continue_idx, n, seed, step, wobble, actions_out);
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
+}
 
 static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
                         int n_rows, int L, float *out, int64_t pitch,
@@ -797,6 +933,7 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
     int *idx_next = env->cur ? d.idx_a : d.idx_b;
     const int L = env->length;
     const int nb = (n_active + BLOCK - 1) / BLOCK;
+    prof_mark(env, 0, 0, s);
 #define TTL_LAUNCH_ADVANCE(M)                                                  \
     hipLaunchKernelGGL((k_advance<M>), dim3(nb), dim3(BLOCK), 0, s, env->P, idx, \
                        actions, noise, n_active, L, reward_out, done_out)
@@ -804,16 +941,22 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
     else if (d.mode == TTL_MODE_F64DIR) TTL_LAUNCH_ADVANCE(TTL_MODE_F64DIR);
     else TTL_LAUNCH_ADVANCE(TTL_MODE_F32NORM);
 #undef TTL_LAUNCH_ADVANCE
+    prof_mark(env, 0, 1, s);
     HIP_TRY(hipGetLastError());
+    prof_mark(env, 1, 0, s);
     hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
                        n_active, nb, order);
+    prof_mark(env, 1, 1, s);
     HIP_TRY(hipGetLastError());
     env->length = L + 1;
     env->stepped = 1;
     env->last_order = order;
     env->last_n = n_active;
-    return launch_state(env, idx, env->P.row_dest, n_active, L + 1, state_out,
-                        state_pitch, s);
+    prof_mark(env, 2, 0, s);
+    const int rc = launch_state(env, idx, env->P.row_dest, n_active, L + 1,
+                                state_out, state_pitch, s);
+    prof_mark(env, 2, 1, s);
+    return rc;
 }
 
 int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,

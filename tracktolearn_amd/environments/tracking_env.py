@@ -241,6 +241,35 @@ class TrackingEnvironment(BaseEnv):
         return self._compute_stopping_flags(streamlines)
 
     # ------------------------------------------------------------------ #
+    # measurement support
+    def scripted_actions(self, state, step, seed=0, wobble=0.05):
+        """Policy stand-in for "env.step only" runs: (n_active, 3)
+        float32 actions on the GPU from ``ttl_scripted_actions``."""
+        n = self._n_active
+        out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ttl_scripted_actions(
+            state.data_ptr(), state.stride(0), 7 * self._n_coef,
+            self._idx_view(n).data_ptr(), n, int(seed) & 0xffffffff,
+            int(step), float(wobble), out.data_ptr(), self._stream()),
+            'ttl_scripted_actions')
+        return out
+
+    def profile_begin(self, max_launches=4096):
+        """Bracket every step kernel with HIP events (ttl_env_profile_begin)."""
+        _lib.check(self._lib.ttl_env_profile_begin(self._handle, max_launches),
+                   'ttl_env_profile_begin')
+
+    def profile_end(self):
+        """{'advance'|'prefix'|'state': (total_ms, n_launches)}."""
+        import ctypes as C
+        ms = (C.c_double * 3)()
+        n = (C.c_int32 * 3)()
+        _lib.check(self._lib.ttl_env_profile_end(self._handle, ms, n),
+                   'ttl_env_profile_end')
+        return {k: (ms[i], n[i]) for i, k in
+                enumerate(('advance', 'prefix', 'state'))}
+
+    # ------------------------------------------------------------------ #
     # host views of the per-streamline state (reference attribute names)
     @property
     def continue_idx(self):

@@ -1,0 +1,104 @@
+"""Multi-GPU layout of the environment path: one process per GPU, streamlines
+sharded, volumes replicated, no collective on the step path.
+
+The reference is single-process.  Streamlines are independent
+given the read-only volumes, so rank r of R tracks the contiguous slice
+``shard_bounds(n, r, R)`` of every seed batch and never talks to its peers
+while stepping.  The only exchange is collating the finished tracts at
+``get_streamlines()`` time: an all-gather of (lengths, flags) followed by an
+all-gather of the ragged points padded to the longest shard -- RCCL over xGMI
+on GPUs (backend "nccl"), gloo in the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from tracktolearn_amd.environments.stopping_criteria import StoppingFlags
+from tracktolearn_amd.tractogram import Tractogram
+
+
+def shard_bounds(n, rank, world):
+    """[start, end) of rank's contiguous shard of n seeds (ceil split; the
+    last shards may be short or empty)."""
+    per = -(-n // world)
+    start = min(rank * per, n)
+    return start, min(start + per, n)
+
+
+def kept_lengths(lengths, flags):
+    """Points kept per streamline: the last point is dropped when CURVATURE or
+    MASK stopped it (TrackToLearn/environments/tracking_env.py:263-284)."""
+    cut = (StoppingFlags.STOPPING_CURVATURE.value |
+           StoppingFlags.STOPPING_MASK.value)
+    return lengths.to(torch.int64) - ((flags & cut) != 0).to(torch.int64)
+
+
+def pack_points(history, keep_len):
+    """Ragged pack on the device: (n, T, 3) history + kept lengths ->
+    (sum(keep_len), 3) points, streamline-major."""
+    steps = torch.arange(history.shape[1], device=history.device)
+    return history[steps[None, :] < keep_len[:, None]]
+
+
+def all_gather_counts(values, group=None):
+    """All-gather one int64 per rank."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(values)], dtype=torch.int64,
+                        device=_coll_device(group))
+    out = torch.empty(world, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.tolist()
+
+
+def _coll_device(group):
+    backend = dist.get_backend(group)
+    if backend == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def all_gather_ragged(rows, group=None):
+    """All-gather tensors whose first dimension differs per rank: pad to the
+    longest shard, one all_gather_into_tensor, cut the padding.  Returns the
+    per-rank pieces in rank order."""
+    world = dist.get_world_size(group)
+    dev = _coll_device(group)
+    rows = rows.to(dev).contiguous()
+    counts = all_gather_counts(rows.shape[0], group)
+    longest = max(max(counts), 1)
+    padded = torch.zeros((longest,) + tuple(rows.shape[1:]), dtype=rows.dtype,
+                         device=dev)
+    padded[:rows.shape[0]] = rows
+    out = torch.empty((world * longest,) + tuple(rows.shape[1:]),
+                      dtype=rows.dtype, device=dev)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return [out[r * longest:r * longest + counts[r]] for r in range(world)]
+
+
+def all_gather_tract_index(env, group=None):
+    """(lengths, flags) of every rank's streamlines, concatenated in rank
+    order (device tensors)."""
+    n = env._n_total
+    lengths = torch.cat(all_gather_ragged(env._buf_lengths[:n], group))
+    flags = torch.cat(all_gather_ragged(env._buf_flags[:n], group))
+    return lengths, flags
+
+
+def all_gather_tractogram(env, group=None):
+    """Every rank's finished tracts as one Tractogram (rank order, then
+    streamline order) -- the sharded ``get_streamlines()``."""
+    n = env._n_total
+    lengths, flags = env._buf_lengths[:n], env._buf_flags[:n]
+    keep = kept_lengths(lengths, flags)
+    points = pack_points(env._buf_streamlines[:n], keep)
+    keep_all = torch.cat(all_gather_ragged(keep, group)).cpu().numpy()
+    flags_all = torch.cat(all_gather_ragged(flags, group)).cpu().numpy()
+    seeds = torch.from_numpy(np.ascontiguousarray(env.initial_points,
+                                                  dtype=np.float64))
+    seeds_all = torch.cat(all_gather_ragged(seeds, group)).cpu().numpy()
+    pts_all = torch.cat(all_gather_ragged(points, group)).cpu().numpy()
+    offsets = np.concatenate(([0], np.cumsum(keep_all)))
+    lines = [pts_all[offsets[i]:offsets[i + 1]] for i in range(len(keep_all))]
+    return Tractogram(streamlines=lines,
+                      data_per_streamline={'seeds': seeds_all,
+                                           'flags': flags_all.astype(np.int64)})
