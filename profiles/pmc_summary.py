@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs for the judged profiles.
+
+    python profiles/pmc_summary.py <tag> <stats_dir> <fetch_dir> <write_dir>
+
+Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --kernel-trace
+--stats), profiles/<tag>_pmc_traffic.txt and profiles/pmc_traffic.json (read
+by bench.py to fill roofline.traffic).
+
+Counter handling follows /opt/skills/guides (cdna_hip_programming.md section 7,
+MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE come from SEPARATE
+--pmc passes (TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2); both are
+in KiB; on gfx950 FETCH_SIZE counts 128-B requests at 64 B, i.e. reads exactly
+half of a wide (16 B/lane) read stream, so the read side is doubled:
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+The guide calibrates that factor for 16-B-per-lane streams only; k_state's
+gather is 16 B per lane, its stores are 4 B per lane (WRITE_SIZE is documented
+exact for 16-B stores and float atomics, other widths "uncalibrated").
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def short(name):
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    m = re.match(r'\s*([A-Za-z_0-9:<>]+)', name)
+    return m.group(1) if m else name
+
+
+def counters(dirname, counter):
+    path = glob.glob(os.path.join(dirname, '**', '*_counter_collection.csv'),
+                     recursive=True)[0]
+    rows = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter:
+            rows[short(r['Kernel_Name'])].append(
+                (float(r['Counter_Value']), int(r['Grid_Size'])))
+    return rows
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    stats = glob.glob(os.path.join(stats_dir, '**', '*_kernel_stats.csv'),
+                      recursive=True)[0]
+    shutil.copy(stats, os.path.join(HERE, f'{tag}_kernel_stats.csv'))
+    fetch = counters(fetch_dir, 'FETCH_SIZE')
+    write = counters(write_dir, 'WRITE_SIZE')
+    lines = ['kernel | launches | FETCH_SIZE KiB avg | WRITE_SIZE KiB avg | '
+             'HBM bytes/launch = (2*FETCH + WRITE)*1024']
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith('k_'):
+            continue
+        f = [v for v, _ in fetch.get(k, [])]
+        w = [v for v, _ in write.get(k, [])]
+        fa = sum(f) / max(len(f), 1)
+        wa = sum(w) / max(len(w), 1)
+        hbm = (2 * fa + wa) * 1024
+        out[k] = dict(launches=len(f), fetch_kib=fa, write_kib=wa,
+                      hbm_bytes_per_launch=hbm)
+        lines.append(f'{k} | {len(f)} | {fa:.1f} | {wa:.1f} | {hbm:.4g}')
+    open(os.path.join(HERE, f'{tag}_pmc_traffic.txt'), 'w').write(
+        '\n'.join(lines) + '\n')
+    state = [k for k in out if k.startswith('k_state')]
+    js = {'source': f'profiles/{tag}_pmc_traffic.txt', 'kernels': out}
+    if state:
+        js['k_state_hbm_bytes_per_launch'] = out[state[0]]['hbm_bytes_per_launch']
+    json.dump(js, open(os.path.join(HERE, 'pmc_traffic.json'), 'w'), indent=1)
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__':
+    main()

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -524,6 +525,201 @@ __global__ __launch_bounds__(BLOCK) void k_state(
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_state_dd: same result as k_state (up to float32 summation order, ~1e-7)
+// with the 56 corner fetches of the 7-point stencil deduplicated in registers.
+// For a neighbourhood radius 0 < r < 1 voxel the shifted points (+-r along one
+// axis) sit in the centre cell or in the adjacent one, so along each axis only
+// the slices f-1 .. f+2 are touched and the other two axes keep the centre's
+// 2x2 footprint and weights.  Per axis: B_s = bilinear blend (other two axes)
+// of slice s; centre / plus / minus points are then 1-D lerps of two B_s.
+// Loads: 8 centre-cell voxels + 4 per outer slice that is really needed
+// (f-1 iff the minus point crosses down, f+2 iff the plus point crosses up):
+// 20..32 records per streamline (26 on average) instead of 56.
+// ---------------------------------------------------------------------------
+struct f4 {
+    float x, y, z, w;
+};
+// 16-byte load at a 32-bit byte offset from a wave-uniform base: lets the
+// compiler use the SGPR-base + VGPR-offset addressing form (one VGPR per
+// address instead of two)
+__device__ __forceinline__ f4 ld4(const char *base, unsigned byte_off) {
+    const float4 v = *reinterpret_cast<const float4 *>(base + byte_off);
+    return f4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ f4 scale4(f4 a, float w) {
+    return f4{a.x * w, a.y * w, a.z * w, a.w * w};
+}
+__device__ __forceinline__ f4 axpy4(f4 acc, f4 a, float w) {  // acc + a*w
+    return f4{acc.x + a.x * w, acc.y + a.y * w, acc.z + a.z * w, acc.w + a.w * w};
+}
+// bilinear blend of 4 records with weights (a0,a1) x (b0,b1)
+__device__ __forceinline__ f4 blend4(f4 v00, f4 v01, f4 v10, f4 v11, float a0,
+                                     float a1, float b0, float b1) {
+    f4 r = scale4(v00, a0 * b0);
+    r = axpy4(r, v01, a0 * b1);
+    r = axpy4(r, v10, a1 * b0);
+    r = axpy4(r, v11, a1 * b1);
+    return r;
+}
+__device__ __forceinline__ f4 lerp4(f4 lo, f4 hi, float d) {
+    return axpy4(scale4(lo, 1.0f - d), hi, d);
+}
+__device__ __forceinline__ f4 sel4(bool c, f4 a, f4 b) {
+    return f4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w};
+}
+__device__ __forceinline__ int clipi(int v, int n) { return min(max(v, 0), n - 1); }
+// store the float4 column c..c+3 of one point's C coefficients (the last
+// column of a padded record may be partial)
+__device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
+    if (c + 3 < C) {
+        o[0] = a.x;
+        o[1] = a.y;
+        o[2] = a.z;
+        o[3] = a.w;
+    } else {
+        if (c + 0 < C) o[0] = a.x;
+        if (c + 1 < C) o[1] = a.y;
+        if (c + 2 < C) o[2] = a.z;
+    }
+}
+
+template <int LPS, int MINW, bool LOOP>
+__global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
+    EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
+    int n_rows, int L, float *__restrict__ out, long long pitch) {
+    constexpr int ROWS = BLOCK / LPS;
+    const int row = blockIdx.x * ROWS + threadIdx.x / LPS;
+    const int sub = threadIdx.x % LPS;
+    if (row >= n_rows) return;
+    const int g = idx ? idx[row] : row;
+    const int r = row_dest ? row_dest[row] : row;
+    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
+    float px = h[(L - 1) * 3 + 0];
+    float py = h[(L - 1) * 3 + 1];
+    float pz = h[(L - 1) * 3 + 2];
+    float *orow = out + (size_t)r * (size_t)pitch;
+    const int C = P.n_coef;
+    const int C4 = P.coef_pitch >> 2;
+    const int X = P.sh_dim[0], Y = P.sh_dim[1], Z = P.sh_dim[2];
+    const char *vol = reinterpret_cast<const char *>(P.sh);
+    const float rad = P.radius;
+
+    // centre / plus / minus coordinates per axis (float32 adds as the
+    // reference's `coords + neighbourhood`), floors and fractions
+    float cxp = px + rad, cxm = px + (-rad);
+    float cyp = py + rad, cym = py + (-rad);
+    float czp = pz + rad, czm = pz + (-rad);
+    if (P.sh_shift != 0.0f) {
+        px += P.sh_shift; py += P.sh_shift; pz += P.sh_shift;
+        cxp += P.sh_shift; cxm += P.sh_shift;
+        cyp += P.sh_shift; cym += P.sh_shift;
+        czp += P.sh_shift; czm += P.sh_shift;
+    }
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const float dx = px - fx, dy = py - fy, dz = pz - fz;
+    const float ex = 1.0f - dx, ey = 1.0f - dy, ez = 1.0f - dz;
+    const float fxp = floorf(cxp), fxm = floorf(cxm);
+    const float fyp = floorf(cyp), fym = floorf(cym);
+    const float fzp = floorf(czp), fzm = floorf(czm);
+    const float dxp = cxp - fxp, dxm = cxm - fxm;
+    const float dyp = cyp - fyp, dym = cym - fym;
+    const float dzp = czp - fzp, dzm = czm - fzm;
+    // does the plus point sit in the next cell / the minus point in the
+    // previous one?  (0 < r < 1 guarantees one cell at most)
+    const bool xup = fxp > fx, xdn = fxm < fx;
+    const bool yup = fyp > fy, ydn = fym < fy;
+    const bool zup = fzp > fz, zdn = fzm < fz;
+    // the float clamp tames NaN / huge coordinates before the int conversion
+    const int ix = (int)fminf(fmaxf(fx, -4.0f), (float)X + 4.0f);
+    const int iy = (int)fminf(fmaxf(fy, -4.0f), (float)Y + 4.0f);
+    const int iz = (int)fminf(fmaxf(fz, -4.0f), (float)Z + 4.0f);
+    // byte offset of a voxel record = ox[.] + oy[.] + oz[.] (32-bit; the host
+    // guarantees the volume < 4 GiB), slices f-1, f, f+1, f+2 clipped per axis
+    const unsigned rec = (unsigned)C4 * 16u;
+    const unsigned sz = rec, sy = rec * (unsigned)Z, sx = sy * (unsigned)Y;
+    const unsigned x0 = clipi(ix - 1, X) * sx, x1 = clipi(ix, X) * sx,
+                   x2 = clipi(ix + 1, X) * sx, x3 = clipi(ix + 2, X) * sx;
+    const unsigned y0 = clipi(iy - 1, Y) * sy, y1 = clipi(iy, Y) * sy,
+                   y2 = clipi(iy + 1, Y) * sy, y3 = clipi(iy + 2, Y) * sy;
+    const unsigned z0 = clipi(iz - 1, Z) * sz, z1 = clipi(iz, Z) * sz,
+                   z2 = clipi(iz + 1, Z) * sz, z3 = clipi(iz + 2, Z) * sz;
+#define TTL_VOX(xo, yo, zo) ((xo) + (yo) + (zo))
+    // one float4 column per lane when the record fits the lane group (LOOP =
+    // false, the usual case: nothing is hoisted and kept live across columns)
+    for (int c4 = sub; c4 < C4; c4 += LPS) {
+        const unsigned cb = (unsigned)c4 * 16u;
+        // centre cell
+        const f4 v000 = ld4(vol, TTL_VOX(x1, y1, z1) + cb), v001 = ld4(vol, TTL_VOX(x1, y1, z2) + cb);
+        const f4 v010 = ld4(vol, TTL_VOX(x1, y2, z1) + cb), v011 = ld4(vol, TTL_VOX(x1, y2, z2) + cb);
+        const f4 v100 = ld4(vol, TTL_VOX(x2, y1, z1) + cb), v101 = ld4(vol, TTL_VOX(x2, y1, z2) + cb);
+        const f4 v110 = ld4(vol, TTL_VOX(x2, y2, z1) + cb), v111 = ld4(vol, TTL_VOX(x2, y2, z2) + cb);
+        const f4 zero{0.f, 0.f, 0.f, 0.f};
+        const int c = c4 * 4;
+        // outer slices are fetched (and reduced to one blended record at once)
+        // only where a shifted point really reaches them
+        // --- x axis: slices blended over (y, z) ---
+        {
+            f4 b0 = zero, b3 = zero;
+            if (xdn)
+                b0 = blend4(ld4(vol, TTL_VOX(x0, y1, z1) + cb), ld4(vol, TTL_VOX(x0, y1, z2) + cb),
+                            ld4(vol, TTL_VOX(x0, y2, z1) + cb), ld4(vol, TTL_VOX(x0, y2, z2) + cb),
+                            ey, dy, ez, dz);
+            if (xup)
+                b3 = blend4(ld4(vol, TTL_VOX(x3, y1, z1) + cb), ld4(vol, TTL_VOX(x3, y1, z2) + cb),
+                            ld4(vol, TTL_VOX(x3, y2, z1) + cb), ld4(vol, TTL_VOX(x3, y2, z2) + cb),
+                            ey, dy, ez, dz);
+            const f4 b1 = blend4(v000, v001, v010, v011, ey, dy, ez, dz);
+            const f4 b2 = blend4(v100, v101, v110, v111, ey, dy, ez, dz);
+            put4(orow + 0 * C + c, lerp4(b1, b2, dx), c, C);
+            put4(orow + 1 * C + c, lerp4(sel4(xup, b2, b1), sel4(xup, b3, b2), dxp), c, C);
+            put4(orow + 4 * C + c, lerp4(sel4(xdn, b0, b1), sel4(xdn, b1, b2), dxm), c, C);
+        }
+        // --- y axis: slices blended over (x, z) ---
+        {
+            f4 b0 = zero, b3 = zero;
+            if (ydn)
+                b0 = blend4(ld4(vol, TTL_VOX(x1, y0, z1) + cb), ld4(vol, TTL_VOX(x1, y0, z2) + cb),
+                            ld4(vol, TTL_VOX(x2, y0, z1) + cb), ld4(vol, TTL_VOX(x2, y0, z2) + cb),
+                            ex, dx, ez, dz);
+            if (yup)
+                b3 = blend4(ld4(vol, TTL_VOX(x1, y3, z1) + cb), ld4(vol, TTL_VOX(x1, y3, z2) + cb),
+                            ld4(vol, TTL_VOX(x2, y3, z1) + cb), ld4(vol, TTL_VOX(x2, y3, z2) + cb),
+                            ex, dx, ez, dz);
+            const f4 b1 = blend4(v000, v001, v100, v101, ex, dx, ez, dz);
+            const f4 b2 = blend4(v010, v011, v110, v111, ex, dx, ez, dz);
+            put4(orow + 2 * C + c, lerp4(sel4(yup, b2, b1), sel4(yup, b3, b2), dyp), c, C);
+            put4(orow + 5 * C + c, lerp4(sel4(ydn, b0, b1), sel4(ydn, b1, b2), dym), c, C);
+        }
+        // --- z axis: slices blended over (x, y) ---
+        {
+            f4 b0 = zero, b3 = zero;
+            if (zdn)
+                b0 = blend4(ld4(vol, TTL_VOX(x1, y1, z0) + cb), ld4(vol, TTL_VOX(x1, y2, z0) + cb),
+                            ld4(vol, TTL_VOX(x2, y1, z0) + cb), ld4(vol, TTL_VOX(x2, y2, z0) + cb),
+                            ex, dx, ey, dy);
+            if (zup)
+                b3 = blend4(ld4(vol, TTL_VOX(x1, y1, z3) + cb), ld4(vol, TTL_VOX(x1, y2, z3) + cb),
+                            ld4(vol, TTL_VOX(x2, y1, z3) + cb), ld4(vol, TTL_VOX(x2, y2, z3) + cb),
+                            ex, dx, ey, dy);
+            const f4 b1 = blend4(v000, v010, v100, v110, ex, dx, ey, dy);
+            const f4 b2 = blend4(v001, v011, v101, v111, ex, dx, ey, dy);
+            put4(orow + 3 * C + c, lerp4(sel4(zup, b2, b1), sel4(zup, b3, b2), dzp), c, C);
+            put4(orow + 6 * C + c, lerp4(sel4(zdn, b0, b1), sel4(zdn, b1, b2), dzm), c, C);
+        }
+        if (!LOOP) break;
+    }
+#undef TTL_VOX
+    float *od = orow + 7 * C;
+    const int n_seg = L - 1;
+    for (int f = sub; f < 3 * P.n_dirs; f += LPS) {
+        const int j = f / 3, comp = f - 3 * j;
+        float v = 0.0f;
+        if (j < n_seg) v = h[(L - 1 - j) * 3 + comp] - h[(L - 2 - j) * 3 + comp];
+        od[f] = v;
+    }
+}
+
 // stopping flags of caller-supplied tails (n_pts points per streamline)
 __global__ __launch_bounds__(BLOCK) void k_probe_flags(
     EnvParams P, const float *__restrict__ tail, int n, int n_pts,
@@ -663,6 +859,7 @@ struct ttl_env {
     int last_order;
     int last_n;      // n_active of the pending step
     // optional per-kernel timing with HIP events on the caller's stream
+    int state_kernel; // 0: k_state (all 56 corner fetches), else k_state_dd
     int prof_on;
     int prof_cap;     // event pairs available per kernel class
     int prof_n[3];    // launches recorded: advance, prefix, state
@@ -789,6 +986,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->stepped = 0;
     e->last_order = TTL_ORDER_ACTIVE;
     e->last_n = 0;
+    e->state_kernel = 4;
+    if (const char *v = getenv("TTL_STATE_KERNEL")) e->state_kernel = atoi(v);
     e->prof_on = 0;
     e->prof_cap = 0;
     for (int k = 0; k < 3; ++k) {
@@ -869,11 +1068,23 @@ static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
                         int n_rows, int L, float *out, int64_t pitch,
                         hipStream_t s) {
     const int C4 = env->P.coef_pitch >> 2;
+    // the register-deduplicated kernel needs the shifted points to stay
+    // within one cell of the centre: 0 < radius < 1 voxel
+    const size_t vol_bytes = (size_t)env->P.sh_dim[0] * env->P.sh_dim[1] *
+                             env->P.sh_dim[2] * env->P.coef_pitch * sizeof(float);
+    const bool dedupe = env->state_kernel != 0 && env->P.radius > 0.0f &&
+                        env->P.radius < 1.0f && vol_bytes < (1ull << 32);
 #define TTL_LAUNCH_STATE(LPS)                                                 \
-    hipLaunchKernelGGL((k_state<LPS>),                                        \
-                       dim3((n_rows + (BLOCK / LPS) - 1) / (BLOCK / LPS)),    \
-                       dim3(BLOCK), 0, s, env->P, idx, row_dest, n_rows, L,   \
-                       out, (long long)pitch)
+    do {                                                                      \
+        const dim3 grid((n_rows + (BLOCK / LPS) - 1) / (BLOCK / LPS));        \
+        if (!dedupe)                                                          \
+            hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, env->P, \
+                               idx, row_dest, n_rows, L, out, (long long)pitch); \
+        else                                                                  \
+            hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32)>), grid, dim3(BLOCK), 0, s, \
+                               env->P, idx, row_dest, n_rows, L, out,         \
+                               (long long)pitch);                             \
+    } while (0)
     if (C4 <= 4) TTL_LAUNCH_STATE(4);
     else if (C4 <= 8) TTL_LAUNCH_STATE(8);
     else if (C4 <= 16) TTL_LAUNCH_STATE(16);
