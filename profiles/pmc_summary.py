@@ -31,8 +31,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def short(name):
     name = name.replace('(anonymous namespace)::', '').replace('void ', '')
-    m = re.match(r'\s*([A-Za-z_0-9:<>]+)', name)
-    return m.group(1) if m else name
+    m = re.match(r'\s*([A-Za-z_0-9:]+(?:<[^()]*>)?)', name)
+    return m.group(1).replace(' ', '') if m else name
 
 
 def counters(dirname, counter):
