@@ -177,7 +177,7 @@ def main():
 
     # ---- timed region -----------------------------------------------------
     counter = {'state': env.reset(0, N_ACTOR), 'step': 0, 'resets': 0}
-    env.profile_begin(max_launches=max(16, args.steps + 8))
+    env.profile_begin(max_launches=max(16, args.steps + 8), classes=('state',))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -186,6 +186,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = env.profile_end()
+
+    # untimed replay of the same steps with every kernel class bracketed, for
+    # the per-kernel breakdown (the timed region only brackets the dominant
+    # kernel to keep the event records out of the other launch gaps)
+    counter2 = {'state': env.reset(0, N_ACTOR), 'step': 0, 'resets': 0}
+    env.profile_begin(max_launches=max(16, args.steps + 8),
+                      classes=('advance', 'prefix', 'state'))
+    run_steps(env, args.steps, seed, counter2)
+    torch.cuda.synchronize()
+    prof_all = env.profile_end()
 
     # ---- collate finished tracts (the path's only exchange step) ----------
     collate_ms = None
@@ -208,8 +218,8 @@ def main():
     if rank == 0:
         whole_b, kern_b = algorithmic_bytes(C, N_DIRS)
         state_ms, state_n = prof['state']
-        adv_ms, adv_n = prof['advance']
-        pre_ms, _ = prof['prefix']
+        adv_ms, adv_n = prof_all['advance']
+        pre_ms, _ = prof_all['prefix']
         avg_launch_s = state_ms / max(state_n, 1) * 1e-3
         units_per_launch = n_units / max(state_n, 1)
         achieved = kern_b * units_per_launch / avg_launch_s / 1e9

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTL_ABI_VERSION 1
+#define TTL_ABI_VERSION 2
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -146,23 +146,31 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
  *   state_out [n_active][state_pitch] f32, row order per `order`
  *   reward_out[n_active] f64 or NULL  (row i = active row i, always)
  *   done_out  [n_active] u8           (row i = active row i, always)
+ *   host_counts pinned host memory, 2 x int32, or NULL: receives
+ *             {n_continue, n_stopped}.  The copy is issued on a side stream
+ *             as soon as the stopping decisions are final -- before the state
+ *             gather has run -- so that ttl_env_wait_counts() returns early
+ *             and the host can queue the next step behind this one.
  * Normalise + scale the action, first-step flip, grow by one point, LENGTH /
  * CURVATURE / MASK stopping tests, flags and dones, alignment reward, new
  * state.  continue_idx itself only changes in ttl_env_harvest(). */
 int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
                  int32_t n_active, int32_t order, float *state_out,
                  int64_t state_pitch, double *reward_out, uint8_t *done_out,
-                 void *hip_stream);
+                 int32_t *host_counts, void *hip_stream);
+
+/* Blocks the calling host thread until the host_counts of the last
+ * ttl_env_step() have landed (not until the step has finished). */
+int ttl_env_wait_counts(ttl_env *env);
 
 /* TrackingEnvironment.harvest (tracking_env.py:223-245): lengths of the
  * streamlines that stopped in the last step, continue_idx <- survivors
  * (stable).  If the last step used ORDER_ACTIVE and state_out != NULL the
  * survivors' rows are copied from state_in (the step's output) to the first
- * n_continue rows of state_out.  host_counts (pinned, 2 x int32) receives
- * {n_continue, n_stopped} once the stream has run. */
+ * n_continue rows of state_out.  After an ORDER_PARTITION step nothing is
+ * launched (the lengths were written by the step itself). */
 int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
-                    int64_t state_pitch, int32_t *host_counts,
-                    void *hip_stream);
+                    int64_t state_pitch, void *hip_stream);
 
 /* BaseEnv._compute_stopping_flags (env.py:567-603) on caller-supplied points:
  * tail [n][3][3] f32 holds the last three points (oldest first) of n
@@ -183,7 +191,8 @@ int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
  * ttl_env_profile_end() synchronises those events and returns, per kernel
  * class {0: advance, 1: prefix, 2: state gather}, the summed duration in ms
  * and the number of launches, then switches profiling off. */
-int ttl_env_profile_begin(ttl_env *env, int32_t max_launches);
+int ttl_env_profile_begin(ttl_env *env, int32_t max_launches,
+                          int32_t class_mask /* bit k = time class k */);
 int ttl_env_profile_end(ttl_env *env, double *total_ms /*[3]*/,
                         int32_t *n_launches /*[3]*/);
 

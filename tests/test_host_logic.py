@@ -49,7 +49,8 @@ def test_create_rejects_bad_descriptors():
     d.mode = 7
     assert lib.ttl_env_create(ctypes.byref(d), ctypes.byref(h)) == -1
     assert b'mode' in lib.ttl_last_error()
-    assert lib.ttl_env_step(None, None, None, 1, 0, None, 0, None, None, None) == -1
+    assert lib.ttl_env_step(None, None, None, 1, 0, None, 0, None, None, None,
+                            None) == -1
     assert lib.ttl_pack_sh_volume(None, None, 1, 1, 4, None) == -1
 
 

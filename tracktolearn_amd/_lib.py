@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MODE_F32 = 0
 MODE_F64DIR = 1
 MODE_F32NORM = 2
@@ -68,14 +68,15 @@ SYMBOLS = {
                                 C.c_int64, C.c_void_p]),
     'ttl_env_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
-                               C.c_void_p, C.c_void_p]),
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttl_env_wait_counts': (C.c_int, [C.c_void_p]),
     'ttl_env_harvest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_int64, C.c_void_p, C.c_void_p]),
+                                  C.c_int64, C.c_void_p]),
     'ttl_env_stopping_flags': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p]),
     'ttl_env_view': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
-    'ttl_env_profile_begin': (C.c_int, [C.c_void_p, C.c_int32]),
+    'ttl_env_profile_begin': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'ttl_env_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_double),
                                       C.POINTER(C.c_int32)]),
     'ttl_scripted_actions': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32,

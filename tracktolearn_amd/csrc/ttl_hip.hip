@@ -130,6 +130,32 @@ __device__ bool outside_mask(const EnvParams &P, float px, float py, float pz) {
     cubic_weights(cy, fy, wy);
     cubic_weights(cz, fz, wz);
     const int sx = (int)fx - 1, sy = (int)fy - 1, sz = (int)fz - 1;
+    double t = 0.0;
+    if (sx >= 0 && sy >= 0 && sz >= 0 && sx + 3 < nx && sy + 3 < ny && sz + 3 < nz) {
+        // interior: no border folding, the 4 z-taps of a (x, y) line are 32
+        // contiguous bytes (8-byte aligned) -> two 16-byte loads
+        struct __attribute__((aligned(8))) taps4 {
+            double v[4];
+        };
+        const double *base = P.mask_coef + ((size_t)sx * ny + sy) * nz + sz;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const taps4 q = *reinterpret_cast<const taps4 *>(
+                    base + ((size_t)a * ny + b) * nz);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    double v = q.v[d];
+                    v = v * wx[a];
+                    v = v * wy[b];
+                    v = v * wz[d];
+                    t = t + v;
+                }
+            }
+        }
+        return t < P.mask_thr;
+    }
     int ix[4], iy[4], iz[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -137,7 +163,6 @@ __device__ bool outside_mask(const EnvParams &P, float px, float py, float pz) {
         iy[j] = mirror_fold(sy + j, ny);
         iz[j] = mirror_fold(sz + j, nz);
     }
-    double t = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
                                                   const int *__restrict__ idx,
                                                   int *__restrict__ idx_next,
                                                   int n_active, int n_blocks,
-                                                  int order) {
+                                                  int order, int n_pts) {
     __shared__ int red[2][BLOCK / 64];
     int before = 0, total = 0;
     for (int b = threadIdx.x; b < n_blocks; b += BLOCK) {
@@ -420,7 +445,11 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
     if (i >= n_active) return;
     const int pos = before + P.rank[i];
     const bool stop = P.stop[i] != 0;
-    if (!stop) idx_next[pos] = idx[i];
+    const int g = idx[i];
+    if (!stop) idx_next[pos] = g;
+    // ORDER_PARTITION has no separate harvest kernel: record the final length
+    // of the streamlines that just stopped here (tracking_env.py:236)
+    if (stop && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
     P.surv_pos[i] = stop ? -1 : pos;
     int dest = i;
     if (order == TTL_ORDER_PARTITION) dest = stop ? total + (i - pos) : pos;
@@ -860,14 +889,21 @@ struct ttl_env {
     int last_n;      // n_active of the pending step
     // optional per-kernel timing with HIP events on the caller's stream
     int state_kernel; // 0: k_state (all 56 corner fetches), else k_state_dd
+    hipStream_t side;      // carries the early device->host copy of the counts
+    hipEvent_t ev_prefix;  // main stream: k_prefix done (counts are final)
+    hipEvent_t ev_counts;  // side stream: counts have landed in host memory
+    int counts_pending;    // an early copy is in flight / unread
     int prof_on;
+    int prof_mask;    // bit k: time kernel class k
     int prof_cap;     // event pairs available per kernel class
     int prof_n[3];    // launches recorded: advance, prefix, state
     hipEvent_t *prof_ev[3];  // [2 * prof_cap] start/stop pairs
 };
 
 static void prof_mark(ttl_env *e, int which, int stop, hipStream_t s) {
-    if (!e->prof_on || e->prof_n[which] >= e->prof_cap) return;
+    if (!e->prof_on || !((e->prof_mask >> which) & 1) ||
+        e->prof_n[which] >= e->prof_cap)
+        return;
     (void)hipEventRecord(e->prof_ev[which][2 * e->prof_n[which] + stop], s);
     if (stop) e->prof_n[which]++;
 }
@@ -988,6 +1024,11 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->last_n = 0;
     e->state_kernel = 4;
     if (const char *v = getenv("TTL_STATE_KERNEL")) e->state_kernel = atoi(v);
+    e->side = nullptr;
+    e->ev_prefix = nullptr;
+    e->ev_counts = nullptr;
+    e->counts_pending = 0;
+    e->prof_mask = 7;
     e->prof_on = 0;
     e->prof_cap = 0;
     for (int k = 0; k < 3; ++k) {
@@ -1014,13 +1055,17 @@ static void prof_free(ttl_env *env) {
 void ttl_env_destroy(ttl_env *env) {
     if (!env) return;
     prof_free(env);
+    if (env->ev_prefix) (void)hipEventDestroy(env->ev_prefix);
+    if (env->ev_counts) (void)hipEventDestroy(env->ev_counts);
+    if (env->side) (void)hipStreamDestroy(env->side);
     delete env;
 }
 
-int ttl_env_profile_begin(ttl_env *env, int32_t max_launches) {
-    if (!env || max_launches < 1 || max_launches > (1 << 20))
+int ttl_env_profile_begin(ttl_env *env, int32_t max_launches, int32_t class_mask) {
+    if (!env || max_launches < 1 || max_launches > (1 << 20) || !(class_mask & 7))
         return fail(TTL_ERR_INVALID, "ttl_env_profile_begin: bad arguments");
     prof_free(env);
+    env->prof_mask = class_mask & 7;
     for (int k = 0; k < 3; ++k) {
         env->prof_ev[k] = new (std::nothrow) hipEvent_t[2 * (size_t)max_launches];
         if (!env->prof_ev[k]) return fail(TTL_ERR_INVALID, "ttl_env_profile_begin: out of host memory");
@@ -1121,7 +1166,7 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n, float *state_out,
 int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
                  int32_t n_active, int32_t order, float *state_out,
                  int64_t state_pitch, double *reward_out, uint8_t *done_out,
-                 void *hip_stream) {
+                 int32_t *host_counts, void *hip_stream) {
     if (!env || !actions || !state_out || !done_out)
         return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
     if (env->length < 1) return fail(TTL_ERR_STATE, "ttl_env_step: reset first");
@@ -1156,9 +1201,25 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
     HIP_TRY(hipGetLastError());
     prof_mark(env, 1, 0, s);
     hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
-                       n_active, nb, order);
+                       n_active, nb, order, L + 1);
     prof_mark(env, 1, 1, s);
     HIP_TRY(hipGetLastError());
+    if (host_counts) {
+        // the survivor count is final once k_prefix has run: ship it to the
+        // host on a side stream now, so the host can queue the next step
+        // while k_state is still running
+        if (!env->side) {
+            HIP_TRY(hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&env->ev_prefix, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&env->ev_counts, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(env->ev_prefix, s));
+        HIP_TRY(hipStreamWaitEvent(env->side, env->ev_prefix, 0));
+        HIP_TRY(hipMemcpyAsync(host_counts, env->P.counts, 2 * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, env->side));
+        HIP_TRY(hipEventRecord(env->ev_counts, env->side));
+        env->counts_pending = 1;
+    }
     env->length = L + 1;
     env->stepped = 1;
     env->last_order = order;
@@ -1171,33 +1232,42 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
 }
 
 int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
-                    int64_t state_pitch, int32_t *host_counts, void *hip_stream) {
-    if (!env || !host_counts)
-        return fail(TTL_ERR_INVALID, "ttl_env_harvest: null argument");
+                    int64_t state_pitch, void *hip_stream) {
+    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_harvest: null handle");
     if (!env->stepped) return fail(TTL_ERR_STATE, "ttl_env_harvest: no step to harvest");
     const ttl_env_desc &d = env->d;
     hipStream_t s = (hipStream_t)hip_stream;
     const int *idx = env->cur ? d.idx_b : d.idx_a;
     const int n = env->last_n;
     const int nb = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(k_finish, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, n,
-                       env->length);
-    HIP_TRY(hipGetLastError());
-    if (env->last_order == TTL_ORDER_ACTIVE && state_out) {
-        if (!state_in)
-            return fail(TTL_ERR_INVALID, "ttl_env_harvest: state_in needed to compact rows");
-        const int width = 7 * d.n_coef + 3 * d.n_dirs;
-        hipLaunchKernelGGL(k_copy_rows, dim3((n + 3) / 4), dim3(BLOCK), 0, s, env->P,
-                           n, width, state_in, state_out, (long long)state_pitch);
+    if (env->last_order == TTL_ORDER_ACTIVE) {
+        hipLaunchKernelGGL(k_finish, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, n,
+                           env->length);
         HIP_TRY(hipGetLastError());
+        if (state_out) {
+            if (!state_in)
+                return fail(TTL_ERR_INVALID, "ttl_env_harvest: state_in needed to compact rows");
+            const int width = 7 * d.n_coef + 3 * d.n_dirs;
+            hipLaunchKernelGGL(k_copy_rows, dim3((n + 3) / 4), dim3(BLOCK), 0, s,
+                               env->P, n, width, state_in, state_out,
+                               (long long)state_pitch);
+            HIP_TRY(hipGetLastError());
+        }
     }
-    HIP_TRY(hipMemcpyAsync(host_counts, env->P.counts, 2 * sizeof(int32_t),
-                           hipMemcpyDeviceToHost, s));
     env->cur ^= 1;
     env->stepped = 0;
     // the caller learns the exact survivor count from host_counts; until then
     // the bound is the previous count
     env->n_active = n;
+    return TTL_OK;
+}
+
+int ttl_env_wait_counts(ttl_env *env) {
+    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_wait_counts: null handle");
+    if (!env->counts_pending)
+        return fail(TTL_ERR_STATE, "ttl_env_wait_counts: the last step had no host_counts");
+    HIP_TRY(hipEventSynchronize(env->ev_counts));
+    env->counts_pending = 0;
     return TTL_OK;
 }
 

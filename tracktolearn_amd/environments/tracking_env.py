@@ -131,7 +131,8 @@ class TrackingEnvironment(BaseEnv):
             noise.data_ptr() if noise is not None else None, n, order,
             state.data_ptr(), self._state_width,
             reward.data_ptr() if reward is not None else None,
-            done.data_ptr(), self._stream()), 'ttl_env_step')
+            done.data_ptr(), self._host_counts.data_ptr(), self._stream()),
+            'ttl_env_step')
         self.length += 1
         self._pending = dict(order=order, state=state, n=n, done=done,
                              keep=(a, noise))
@@ -187,8 +188,12 @@ class TrackingEnvironment(BaseEnv):
         """Drop the streamlines that stopped in the last step
         (tracking_env.py:223-245).  Returns ``(state, not_stopping)``: the
         state rows of the streamlines still being tracked, and the boolean
-        mask over the previous active rows: host numpy after ``step()`` (as
-        the reference), a GPU bool tensor after ``step_device()``."""
+        mask over the previous active rows (host numpy, as the reference).
+        After ``step_device()`` the mask is ``None``: the caller already holds
+        the ``dones`` GPU tensor of that step (``not_stopping == (dones == 0)``).
+
+        Only the 8-byte survivor count is waited for, not the step itself: the
+        returned tensor is stream-ordered like any other torch result."""
         if self._pending is None:
             raise RuntimeError('no step to harvest')
         pend = self._pending
@@ -201,8 +206,11 @@ class TrackingEnvironment(BaseEnv):
         _lib.check(self._lib.ttl_env_harvest(
             self._handle, state_in.data_ptr(),
             out.data_ptr() if out is not None else None, self._state_width,
-            self._host_counts.data_ptr(), self._stream()), 'ttl_env_harvest')
-        torch.cuda.current_stream(self.device).synchronize()
+            self._stream()), 'ttl_env_harvest')
+        # the survivor count left the GPU right after the stopping decisions
+        # (side stream): this wait does not cover the state gather
+        _lib.check(self._lib.ttl_env_wait_counts(self._handle),
+                   'ttl_env_wait_counts')
         n_cont = int(self._host_counts[0])
         if order == _lib.ORDER_ACTIVE:
             new_state = out[:n_cont]
@@ -211,7 +219,7 @@ class TrackingEnvironment(BaseEnv):
         if 'dones_host' in pend:
             self.not_stopping = np.logical_not(pend['dones_host'])
         else:
-            self.not_stopping = pend['done'] == 0
+            self.not_stopping = None
         self._cur ^= 1
         self._n_active = n_cont
         self._pending = None
@@ -254,10 +262,12 @@ class TrackingEnvironment(BaseEnv):
             'ttl_scripted_actions')
         return out
 
-    def profile_begin(self, max_launches=4096):
-        """Bracket every step kernel with HIP events (ttl_env_profile_begin)."""
-        _lib.check(self._lib.ttl_env_profile_begin(self._handle, max_launches),
-                   'ttl_env_profile_begin')
+    def profile_begin(self, max_launches=4096, classes=('state',)):
+        """Bracket the step kernels of the given classes ('advance', 'prefix',
+        'state') with HIP events on the launch stream."""
+        mask = sum(1 << ('advance', 'prefix', 'state').index(c) for c in classes)
+        _lib.check(self._lib.ttl_env_profile_begin(self._handle, max_launches,
+                                                   mask), 'ttl_env_profile_begin')
 
     def profile_end(self):
         """{'advance'|'prefix'|'state': (total_ms, n_launches)}."""
