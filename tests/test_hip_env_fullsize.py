@@ -1,0 +1,157 @@
+"""GPU parity at BASELINE.json's full sizes.
+
+ * config 2 (96^3 x 45, n_actor = 262144, K = 4): the first steps against the
+   CPU oracle on every row, then the whole episode through size-independent
+   properties (stable compaction, count conservation, flag/length/done
+   consistency) and the equality of the two row orders.
+ * config 4's per-GPU shard (145^3 x 45, 131072 streamlines, K = 100, noisy
+   float64 mode): first steps against the oracle, both row orders.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _make(D, N, K, *, noisy, reward, max_length, affine=np.float32, seed=5):
+    from tracktolearn_amd.environments import (NoisyTrackingEnvironment,
+                                               TrackingEnvironment)
+    from tracktolearn_amd.utils.synthetic import (synthetic_seeds,
+                                                  synthetic_subject)
+    subject = synthetic_subject(D, 45, seed=1234, peaks=reward,
+                                affine_dtype=affine)
+    dto = dict(n_dirs=K, theta=30.0, npv=1, binary_stopping_threshold=0.1,
+               step_size=0.75, min_length=20.0, max_length=max_length,
+               compute_reward=reward, alignment_weighting=1.0, oracle_bonus=0.0,
+               rng=np.random.RandomState(0), device=torch.device('cuda:0'),
+               target_sh_order=8, noise=0.0, fa_map=None)
+    cls = NoisyTrackingEnvironment if noisy else TrackingEnvironment
+    env = cls(subject, 'testing', dto)
+    env.seeds = synthetic_seeds(subject[1].data, N, seed=seed)
+    return env, subject
+
+
+def _oracle(env, subject, *, noisy, K, reward):
+    from oracle import env_oracle as orc
+    kw = dict(n_dirs=K, theta=30.0, step_size=env.step_size,
+              max_nb_steps=env.max_nb_steps, mask_threshold=0.1,
+              peaks=subject[3].data if reward else None, compute_reward=reward,
+              alignment_weighting=1.0, spline_eval='scipy')
+    cls = orc.OracleNoisyTrackingEnv if noisy else orc.OracleTrackingEnv
+    extra = dict(noise=0.0) if noisy else {}
+    return cls(subject[0].data, subject[1].data, env.seeds, **extra, **kw)
+
+
+def _first_steps_vs_oracle(env, ref, N, n_steps, W):
+    from oracle.scripted_policy import scripted_actions
+    s_hip, s_ref = env.reset(0, N), ref.reset(0, N)
+    assert np.abs(s_hip.cpu().numpy() - s_ref).max() <= TOL
+    for step in range(n_steps):
+        idx = ref.continue_idx
+        a_gpu = env.scripted_actions(s_hip, step, seed=3, wobble=0.05)
+        a_ref = scripted_actions(s_ref, 7 * 45, idx, 3, step, 0.05)
+        if step == 0:     # the GPU generator and its numpy twin agree bit for bit
+            assert np.array_equal(a_gpu.cpu().numpy(), a_ref)
+        ns_hip, r_hip, d_hip, info = env.step(a_ref.copy())
+        ns_ref, r_ref, d_ref, _ = ref.step(a_ref.copy())
+        assert np.array_equal(d_hip, d_ref)                       # bit-exact masks
+        assert np.abs(ns_hip.cpu().numpy() - ns_ref).max() <= TOL
+        assert np.abs(r_hip - r_ref).max() <= TOL
+        s_hip, _ = env.harvest()
+        s_ref, _ = ref.harvest()
+        assert np.array_equal(env.continue_idx, ref.continue_idx)
+    n = env._n_total
+    L = env.length
+    assert np.array_equal(env._buf_streamlines[:n, :L].cpu().numpy(),
+                          ref.streamlines[:, :L])                # bit-identical
+    assert np.array_equal(env.flags, ref.flags)
+    assert np.array_equal(env.lengths, ref.lengths)
+
+
+def test_config2_first_steps_match_oracle():
+    N = 262144
+    env, subject = _make(96, N, 4, noisy=False, reward=True, max_length=200.0)
+    ref = _oracle(env, subject, noisy=False, K=4, reward=True)
+    _first_steps_vs_oracle(env, ref, N, 3, 327)
+
+
+def _run_episode(env, N, order, check):
+    state = env.reset(0, N)
+    step = 0
+    prev_idx = torch.arange(N, device='cuda', dtype=torch.int32)
+    total_stopped = 0
+    digest = torch.zeros((), dtype=torch.float64, device='cuda')
+    while env._n_active:
+        n = env._n_active
+        a = env.scripted_actions(state, step, seed=9, wobble=0.05)
+        if order == 'partition':
+            nstate, _, done, info = env.step_device(a)
+            dest = info['row_dest'].long()
+            rows = nstate[dest]                       # active-row order
+        else:
+            nstate, _, dones_np, _ = env.step(a)
+            done = torch.from_numpy(dones_np).cuda()
+            rows = nstate
+        # a checksum of row checksums, independent of the row order
+        digest += rows.double().sum(dim=1).nan_to_num().sum() * (step + 1)
+        state, _ = env.harvest()
+        if check:
+            idx = env._idx_view(env._n_active)
+            keep = done == 0
+            # stable compaction: survivors keep their order
+            assert torch.equal(idx, prev_idx[:n][keep])
+            if order == 'partition':
+                # survivors' rows are the leading rows, in order
+                assert torch.equal(dest[keep],
+                                   torch.arange(int(keep.sum()), device='cuda'))
+            n_stop = int((~keep).sum())
+            assert env._n_active + n_stop == n              # count conservation
+            total_stopped += n_stop
+            prev_idx = idx.clone()
+        step += 1
+    if check:
+        assert total_stopped == N
+    return step, float(digest)
+
+
+def test_config2_full_episode_properties_and_row_orders():
+    N = 262144
+    env, _ = _make(96, N, 4, noisy=False, reward=False, max_length=200.0)
+    steps_p, dig_p = _run_episode(env, N, 'partition', check=True)
+    flags_p, lengths_p = env.flags, env.lengths
+    hist_p = env._buf_streamlines[:N].clone()
+    assert steps_p <= env.max_nb_steps
+    # every streamline stopped exactly once, for a recorded reason
+    assert (flags_p != 0).all() and env.dones.all()
+    assert lengths_p.min() >= 2 and lengths_p.max() == steps_p + 1
+    # LENGTH can only be raised at the very last possible step
+    too_long = (flags_p & 2) != 0
+    assert (lengths_p[too_long] == env.max_nb_steps).all()
+    # points beyond the final length were never written
+    tail = torch.arange(hist_p.shape[1], device='cuda')[None, :, None] >= \
+        torch.from_numpy(lengths_p).cuda()[:, None, None]
+    assert float((hist_p * tail).abs().max()) == 0.0
+    # the reference-order loop produces the same tracts, bit for bit
+    steps_a, dig_a = _run_episode(env, N, 'active', check=False)
+    assert steps_a == steps_p and dig_a == dig_p
+    assert np.array_equal(env.flags, flags_p)
+    assert np.array_equal(env.lengths, lengths_p)
+    assert torch.equal(env._buf_streamlines[:N], hist_p)
+    # get_streamlines: ragged lengths follow the truncation rule
+    tg = env.get_streamlines()
+    cut = ((flags_p & 4) != 0) | ((flags_p & 1) != 0)
+    assert np.array_equal([len(s) for s in tg.streamlines[:5000]],
+                          (lengths_p - cut)[:5000])
+
+
+def test_config4_shard_first_steps_match_oracle():
+    """145^3 volume (549 MB, larger than the Infinity Cache), one GPU's shard of
+    config 4: 131072 streamlines, K = 100, noisy env (float64 directions)."""
+    N = 131072
+    env, subject = _make(145, N, 100, noisy=True, reward=False,
+                         max_length=300.0, affine=np.float64)
+    ref = _oracle(env, subject, noisy=True, K=100, reward=False)
+    _first_steps_vs_oracle(env, ref, N, 2, 615)
