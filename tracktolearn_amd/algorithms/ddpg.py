@@ -1,0 +1,140 @@
+"""DDPG and the training episode loop shared by every off-policy learner.
+
+Mirror of TrackToLearn/algorithms/ddpg.py (DDPG.__init__, sample_action,
+_episode, update).  The loop keeps the reference's schedule -- one gradient
+update per environment step once ``t >= start_timesteps``, ``t += n_active``
+(ddpg.py:202-219) -- but every tensor stays in HBM: transitions go
+from the env kernels into the device replay ring and batches are gathered on
+the device.
+"""
+import copy
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from tracktolearn_amd.algorithms.rl import RLAlgorithm
+from tracktolearn_amd.algorithms.shared.offpolicy import ActorCritic
+from tracktolearn_amd.algorithms.shared.replay import OffPolicyReplayBuffer
+from tracktolearn_amd.algorithms.shared.utils import add_item_to_means
+from tracktolearn_amd.utils.torch_utils import get_device
+
+
+class DDPG(RLAlgorithm):
+    """Deep deterministic policy gradient (Lillicrap et al. 2015), as adapted
+    to tractography by the reference (ddpg.py:20-139)."""
+
+    agent_cls = ActorCritic
+
+    def __init__(self, input_size, action_size, hidden_dims, action_std=0.35,
+                 lr=3e-4, gamma=0.99, n_actors=4096, batch_size=2 ** 12,
+                 replay_size=1e6, rng=None, device=None):
+        device = device if device is not None else get_device()
+        self.input_size = input_size
+        self.action_size = action_size
+        self.lr = lr
+        self.gamma = gamma
+        self.rng = rng
+        self.device = device
+        self.n_actors = n_actors
+
+        self.agent = self.agent_cls(input_size, action_size, hidden_dims, device)
+        self.target = copy.deepcopy(self.agent)
+        self.actor_optimizer = torch.optim.Adam(
+            self.agent.actor.parameters(), lr=lr)
+        self.critic_optimizer = torch.optim.Adam(
+            self.agent.critic.parameters(), lr=lr)
+
+        self.action_std = action_std
+        self.max_action = 1.
+        self.on_policy = False
+        self.start_timesteps = 1000
+        self.total_it = 0
+        self.tau = 0.005
+        self.batch_size = batch_size
+        self.replay_size = replay_size
+        self.replay_buffer = OffPolicyReplayBuffer(
+            input_size, action_size, max_size=replay_size, device=device)
+        self.t = 1
+
+    # ------------------------------------------------------------------ #
+    def sample_action(self, state):
+        """Policy action + gaussian exploration noise (ddpg.py:120-139)."""
+        with torch.no_grad():
+            a = self.agent.select_action(state)
+            return a + torch.randn_like(a) * (self.max_action * self.action_std)
+
+    def _polyak(self):
+        """target <- tau * online + (1 - tau) * target, critic then actor."""
+        with torch.no_grad():
+            for net, tgt in ((self.agent.critic, self.target.critic),
+                             (self.agent.actor, self.target.actor)):
+                for p, tp in zip(net.parameters(), tgt.parameters()):
+                    tp.data.copy_(self.tau * p.data + (1 - self.tau) * tp.data)
+
+    def _episode(self, initial_state, env):
+        """Track one batch of streamlines to exhaustion while learning
+        (ddpg.py:141-232).  Returns (running_reward, running_losses,
+        episode_length, running_reward_factors)."""
+        reward_sum = torch.zeros((), dtype=torch.float64, device=self.device)
+        state = initial_state
+        running_losses = defaultdict(list)
+        factor_means = []
+        episode_length = 0
+        while state.shape[0] > 0:
+            with torch.no_grad():
+                action = self.sample_action(state)
+            n = action.shape[0]
+            next_state, reward, done, info = env.step_device(action)
+            if reward is None:
+                reward = torch.zeros(n, dtype=torch.float64, device=self.device)
+            else:
+                factor_means.append(reward.mean())
+            # n transitions, as if n agents were gathering them (ddpg.py:194-207)
+            self.replay_buffer.add_partitioned(
+                state, action, next_state, info['row_dest'], reward, done)
+            reward_sum += reward.sum()
+            if self.t >= self.start_timesteps:
+                batch = self.replay_buffer.sample(self.batch_size)
+                losses = self.update(batch)
+                running_losses = add_item_to_means(running_losses, losses)
+            self.t += n
+            state, _ = env.harvest()
+            episode_length += 1
+        running_reward_factors = defaultdict(list)
+        if factor_means:
+            peaks = torch.stack(factor_means).cpu().numpy()
+            running_reward_factors = {
+                'peaks_reward': list(peaks),
+                'oracle_reward': [np.float64(0.0)] * len(peaks)}
+        return (float(reward_sum), running_losses, episode_length,
+                running_reward_factors)
+
+    # ------------------------------------------------------------------ #
+    def update(self, batch):
+        """ddpg.py:234-319: critic regression on the noisy target action,
+        then policy ascent through the critic, then Polyak averaging."""
+        self.total_it += 1
+        state, action, next_state, reward, not_done = batch
+        with torch.no_grad():
+            noise = torch.randn_like(action) * (self.action_std * 2)
+            next_action = self.target.actor(next_state) + noise
+            target_Q = self.target.critic(next_state, next_action)
+            target_Q = reward + not_done * self.gamma * target_Q
+        current_Q = self.agent.critic(state, action)
+        critic_loss = F.mse_loss(current_Q, target_Q)
+        self.critic_optimizer.zero_grad()
+        critic_loss.backward()
+        self.critic_optimizer.step()
+
+        actor_loss = -self.agent.critic(state, self.agent.actor(state)).mean()
+        self.actor_optimizer.zero_grad()
+        actor_loss.backward()
+        self.actor_optimizer.step()
+        losses = {'actor_loss': actor_loss.detach(),
+                  'critic_loss': critic_loss.detach(),
+                  'Q': current_Q.mean().detach(),
+                  'Q\'': target_Q.mean().detach()}
+        self._polyak()
+        return losses

@@ -1,0 +1,163 @@
+"""Actor / critic networks of the off-policy learners, on PyTorch-ROCm (the
+MLP GEMMs run on the MI355X matrix cores through rocBLAS/hipBLASLt).
+
+Same module names, constructor arguments, forward contracts and state_dict
+keys (``layers.N.*``, ``q1.N.*``, ``q2.N.*``) as
+TrackToLearn/algorithms/shared/offpolicy.py, so checkpoints are
+interchangeable.  The gaussian draw of the max-entropy actor can be injected
+(``eps=``) for known-answer tests.
+"""
+import math
+from os.path import join as pjoin
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from tracktolearn_amd.algorithms.shared.utils import (format_widths,
+                                                      make_fc_network)
+
+LOG_STD_MAX = 2
+LOG_STD_MIN = -20
+_HALF_LOG_2PI = math.log(math.sqrt(2 * math.pi))
+
+
+class Actor(nn.Module):
+    """Deterministic policy: state -> tanh(MLP(state)) (offpolicy.py:18-60)."""
+
+    def __init__(self, state_dim, action_dim, hidden_dims, output_activation=nn.Tanh):
+        super().__init__()
+        self.action_dim = action_dim
+        self.hidden_layers = format_widths(hidden_dims)
+        self.layers = make_fc_network(self.hidden_layers, state_dim, action_dim)
+        self.output_activation = output_activation()
+
+    def forward(self, state):
+        return self.output_activation(self.layers(state))
+
+
+class MaxEntropyActor(Actor):
+    """Squashed-gaussian policy of SAC (offpolicy.py:62-140): the MLP emits
+    mean || log_std; returns (tanh(u), log pi(u)) with the tanh correction."""
+
+    def __init__(self, state_dim, action_dim, hidden_dims):
+        super().__init__(state_dim, action_dim, hidden_dims)
+        self.layers = make_fc_network(self.hidden_layers, state_dim,
+                                      action_dim * 2)
+
+    def forward(self, state, probabilistic, eps=None):
+        p = self.layers(state)
+        mu = p[:, :self.action_dim]
+        log_std = torch.clamp(p[:, self.action_dim:], LOG_STD_MIN, LOG_STD_MAX)
+        std = torch.exp(log_std) * probabilistic
+        if eps is None:
+            eps = torch.randn_like(mu)
+        u = mu + eps * std                       # reparametrised sample
+        # log N(u; mu, std), summed over the action, then the tanh correction
+        # 2 (log 2 - u - softplus(-2u))  (SAC, arXiv 1801.01290 app. C)
+        var = std ** 2
+        logp = (-((u - mu) ** 2) / (2 * var) - std.log() - _HALF_LOG_2PI).sum(axis=-1)
+        logp = logp - (2 * (np.log(2) - u - F.softplus(-2 * u))).sum(axis=1)
+        return self.output_activation(u), logp
+
+
+class Critic(nn.Module):
+    """Q(s, a) (offpolicy.py:143-181)."""
+
+    def __init__(self, state_dim, action_dim, hidden_dims):
+        super().__init__()
+        self.hidden_layers = format_widths(hidden_dims)
+        self.q1 = make_fc_network(self.hidden_layers, state_dim + action_dim, 1)
+
+    def forward(self, state, action):
+        return self.q1(torch.cat([state, action], -1)).squeeze(-1)
+
+
+class DoubleCritic(Critic):
+    """Two independent Q networks (offpolicy.py:183-238)."""
+
+    def __init__(self, state_dim, action_dim, hidden_dims, critic_size_factor=1):
+        super().__init__(state_dim, action_dim, hidden_dims)
+        self.hidden_layers = format_widths(hidden_dims) * critic_size_factor
+        self.q1 = make_fc_network(self.hidden_layers, state_dim + action_dim, 1)
+        self.q2 = make_fc_network(self.hidden_layers, state_dim + action_dim, 1)
+
+    def forward(self, state, action):
+        sa = torch.cat([state, action], -1)
+        return self.q1(sa).squeeze(-1), self.q2(sa).squeeze(-1)
+
+    def Q1(self, state, action):
+        return self.q1(torch.cat([state, action], -1)).squeeze(-1)
+
+
+class ActorCritic(object):
+    """Actor + critic pair with the save/load conventions of
+    offpolicy.py:240-376 (``<name>_actor.pth`` / ``<name>_critic.pth``)."""
+
+    actor_cls = Actor
+    critic_cls = Critic
+
+    def __init__(self, state_dim, action_dim, hidden_dims, device):
+        self.device = device
+        self.actor = self.actor_cls(state_dim, action_dim, hidden_dims).to(device)
+        self.critic = self.critic_cls(state_dim, action_dim, hidden_dims).to(device)
+
+    def act(self, state):
+        return self.actor(state)
+
+    def select_action(self, state, probabilistic=0.0):
+        if len(state.shape) < 2:
+            state = state[None, :]
+        return self.act(state)
+
+    def parameters(self):
+        return self.actor.parameters()
+
+    def load_state_dict(self, state_dict):
+        actor_state_dict, critic_state_dict = state_dict
+        self.actor.load_state_dict(actor_state_dict)
+        self.critic.load_state_dict(critic_state_dict)
+
+    def state_dict(self):
+        return self.actor.state_dict(), self.critic.state_dict()
+
+    def save(self, path, filename):
+        torch.save(self.critic.state_dict(), pjoin(path, filename + '_critic.pth'))
+        torch.save(self.actor.state_dict(), pjoin(path, filename + '_actor.pth'))
+
+    def load(self, path, filename):
+        self.critic.load_state_dict(torch.load(
+            pjoin(path, filename + '_critic.pth'), map_location=self.device,
+            weights_only=True))
+        self.actor.load_state_dict(torch.load(
+            pjoin(path, filename + '_actor.pth'), map_location=self.device,
+            weights_only=True))
+
+    def eval(self):
+        self.actor.eval()
+        self.critic.eval()
+
+    def train(self):
+        self.actor.train()
+        self.critic.train()
+
+
+class TD3ActorCritic(ActorCritic):
+    """Deterministic actor + double critic (offpolicy.py:379-412)."""
+    critic_cls = DoubleCritic
+
+
+class SACActorCritic(ActorCritic):
+    """Max-entropy actor + double critic (offpolicy.py:415-482)."""
+    actor_cls = MaxEntropyActor
+    critic_cls = DoubleCritic
+
+    def act(self, state, probabilistic=1.0, eps=None):
+        return self.actor(state, probabilistic, eps=eps)
+
+    def select_action(self, state, probabilistic=1.0):
+        if len(state.shape) < 2:
+            state = state[None, :]
+        action, _ = self.act(state, probabilistic)
+        return action

@@ -1,0 +1,88 @@
+"""HBM-resident replay ring.
+
+The reference keeps the ring in pinned host memory and moves every transition
+device->host at each step and every sampled batch host->device
+(TrackToLearn/algorithms/shared/replay.py:38-143).  Here the five
+ring tensors live on the GPU (10^6 x (2W+5) floats = 2.6 GB at W = 327, out
+of 288 GB), ``add`` is a device scatter and ``sample`` a device gather, so
+nothing crosses PCIe.  Ring arithmetic (``ptr``, ``size``, modulo wrap) and
+sampling without replacement (``randperm(size)[:batch]``) follow the
+reference.
+"""
+import numpy as np
+import torch
+
+from tracktolearn_amd.utils.torch_utils import get_device
+
+
+class OffPolicyReplayBuffer(object):
+
+    def __init__(self, state_dim, action_dim, max_size=int(1e6), device=None):
+        self.device = torch.device(device) if device is not None else get_device()
+        self.max_size = int(max_size)
+        self.ptr = 0
+        self.size = 0
+        kw = dict(dtype=torch.float32, device=self.device)
+        self.state = torch.zeros((self.max_size, state_dim), **kw)
+        self.action = torch.zeros((self.max_size, action_dim), **kw)
+        self.next_state = torch.zeros((self.max_size, state_dim), **kw)
+        self.reward = torch.zeros((self.max_size, 1), **kw)
+        self.not_done = torch.zeros((self.max_size, 1), **kw)
+
+    def _dev(self, x):
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x))
+        return x.to(device=self.device, dtype=torch.float32)
+
+    def _slots(self, n):
+        return (torch.arange(n, device=self.device) + self.ptr) % self.max_size
+
+    def _advance(self, n):
+        self.ptr = (self.ptr + n) % self.max_size
+        self.size = min(self.size + n, self.max_size)
+
+    def add(self, state, action, next_state, reward, done):
+        """Append a batch of transitions (replay.py:56-89).  ``reward`` and
+        ``done`` are (n, 1) or (n,)."""
+        n = len(state)
+        ind = self._slots(n)
+        self.state[ind] = self._dev(state)
+        self.action[ind] = self._dev(action)
+        self.next_state[ind] = self._dev(next_state)
+        self.reward[ind] = self._dev(reward).reshape(n, 1)
+        self.not_done[ind] = 1. - self._dev(done).reshape(n, 1)
+        self._advance(n)
+
+    def add_partitioned(self, state, action, next_state, row_dest, reward, done):
+        """Same as ``add`` when ``next_state`` comes from
+        ``env.step_device()``: its row ``row_dest[i]`` belongs to transition
+        ``i``.  The rows are scattered straight into the ring slots of their
+        transitions, no intermediate re-ordering copy."""
+        n = len(state)
+        ind = self._slots(n)
+        self.state[ind] = self._dev(state)
+        self.action[ind] = self._dev(action)
+        slot_of_row = torch.empty_like(ind)
+        slot_of_row[row_dest.long()] = ind
+        self.next_state[slot_of_row] = next_state
+        self.reward[ind] = self._dev(reward).reshape(n, 1)
+        self.not_done[ind] = 1. - self._dev(done).reshape(n, 1)
+        self._advance(n)
+
+    def __len__(self):
+        return self.size
+
+    def sample(self, batch_size=4096):
+        """min(batch_size, size) transitions without replacement
+        (replay.py:94-143): (s, a, s', r, not_done) on the buffer's device."""
+        ind = torch.randperm(self.size, device=self.device)[
+            :min(self.size, batch_size)]
+        return (self.state.index_select(0, ind),
+                self.action.index_select(0, ind),
+                self.next_state.index_select(0, ind),
+                self.reward.index_select(0, ind).squeeze(-1),
+                self.not_done.index_select(0, ind).squeeze(-1))
+
+    def clear_memory(self):
+        self.ptr = 0
+        self.size = 0
