@@ -1,0 +1,160 @@
+"""GPU tests of the callers of the env path: validation_episode, the training
+episode (_episode) with the HBM replay ring, and the Tracker."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+DEV = 'cuda:0'
+
+
+def _env(D, N, K, *, noisy, reward, max_length=30.0, seed=3):
+    from tracktolearn_amd.environments import (NoisyTrackingEnvironment,
+                                               TrackingEnvironment)
+    from tracktolearn_amd.utils.synthetic import (synthetic_seeds,
+                                                  synthetic_subject)
+    subject = synthetic_subject(D, 45, seed=1234, peaks=True,
+                                affine_dtype=np.float32)
+    dto = dict(n_dirs=K, theta=30.0, npv=1, binary_stopping_threshold=0.1,
+               step_size=0.75, min_length=2.0, max_length=max_length,
+               compute_reward=reward, alignment_weighting=1.0, oracle_bonus=0.0,
+               rng=np.random.RandomState(0), device=torch.device(DEV),
+               target_sh_order=8, noise=0.0, fa_map=None)
+    cls = NoisyTrackingEnvironment if noisy else TrackingEnvironment
+    env = cls(subject, 'testing', dto)
+    env.seeds = synthetic_seeds(subject[1].data, N, seed=seed)
+    return env, subject
+
+
+def _oracle(env, subject, *, noisy, K, reward):
+    from oracle import env_oracle as orc
+    kw = dict(n_dirs=K, theta=30.0, step_size=env.step_size,
+              max_nb_steps=env.max_nb_steps, mask_threshold=0.1,
+              peaks=subject[3].data, compute_reward=reward,
+              alignment_weighting=1.0)
+    if noisy:
+        return orc.OracleNoisyTrackingEnv(subject[0].data, subject[1].data,
+                                          env.seeds, noise=0.0, **kw)
+    return orc.OracleTrackingEnv(subject[0].data, subject[1].data, env.seeds, **kw)
+
+
+class _Recorder:
+    """Wraps an agent's select_action and keeps every action batch."""
+
+    def __init__(self, agent):
+        self.agent, self.actions = agent, []
+        self._orig = agent.select_action
+        agent.select_action = self
+
+    def __call__(self, state, probabilistic=1.0):
+        a = self._orig(state, probabilistic=probabilistic)
+        self.actions.append(a.detach().cpu().numpy().copy())
+        return a
+
+
+def test_validation_episode_tracks_like_the_oracle():
+    """A random-init SACAuto policy tracks 2048 streamlines with the noisy
+    (tracking) env; replaying the recorded actions through the CPU oracle
+    gives the same tractogram, bit for bit."""
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    from tracktolearn_amd.tracking.tracker import Tracker
+    torch.manual_seed(0)
+    N, K = 2048, 4
+    env, subject = _env(20, N, K, noisy=True, reward=True)
+    alg = SACAuto(env.get_state_size(), 3, '64-64', n_actors=N, rng=None,
+                  device=torch.device(DEV))
+    rec = _Recorder(alg.agent)
+    tracker = Tracker(alg, n_actor=N, prob=0.0)
+    tractogram, reward = tracker.track_and_validate(env)
+    assert len(tractogram) == N and np.isfinite(reward)
+
+    ref = _oracle(env, subject, noisy=True, K=K, reward=True)
+    ref.reset(0, N)
+    total = 0.0
+    for a in rec.actions:
+        _, r, _, _ = ref.step(a)
+        total += float(np.sum(r))
+        ref.harvest()
+    assert len(ref.continue_idx) == 0
+    lines, seeds, flags = ref.get_streamlines()
+    assert np.array_equal(tractogram.data_per_streamline['flags'], flags)
+    for got, want in zip(tractogram.streamlines, lines):
+        assert np.array_equal(got, want)
+    assert abs(reward - total) <= 1e-5 * max(1.0, abs(total))
+
+
+def test_training_episode_fills_the_replay_ring_correctly():
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    from tracktolearn_amd.tracking.tracker import Tracker
+    torch.manual_seed(1)
+    np.random.seed(1)
+    N, K = 1024, 4
+    env, subject = _env(20, N, K, noisy=False, reward=True)
+    W = env.get_state_size()
+    alg = SACAuto(W, 3, '64-64', n_actors=N, batch_size=256, replay_size=50000,
+                  rng=None, device=torch.device(DEV))
+    alg.start_timesteps = N               # one step of pure collection first
+    before = [p.detach().clone() for p in alg.agent.actor.parameters()]
+    rec = _Recorder(alg.agent)
+    tracker = Tracker(alg, n_actor=N)
+    tractogram, losses, reward, factors = tracker.track_and_train(env)
+    n_steps = len(rec.actions)
+    n_transitions = sum(len(a) for a in rec.actions)
+    assert len(tractogram) == N
+    assert alg.t == 1 + n_transitions
+    assert len(alg.replay_buffer) == n_transitions
+    assert alg.total_it > 0
+    assert any(not torch.equal(b, p.detach())
+               for b, p in zip(before, alg.agent.actor.parameters()))
+    assert len(factors['peaks_reward']) == n_steps
+
+    # the transitions of the first steps, against the CPU oracle fed with the
+    # same (stochastic) actions: rows aligned as (s, a, s', r, 1 - done)
+    ref = _oracle(env, subject, noisy=False, K=K, reward=True)
+    ref.seeds = np.asarray(env.initial_points)
+    s_ref = ref.reset(0, N)
+    ptr = 0
+    buf = alg.replay_buffer
+    total = 0.0
+    for step, a in enumerate(rec.actions):
+        n = len(a)
+        ns_ref, r_ref, d_ref, _ = ref.step(a.copy())
+        total += float(r_ref.sum())
+        if step < 4:
+            sl = slice(ptr, ptr + n)
+            assert np.abs(buf.state[sl].cpu().numpy() - s_ref).max() <= TOL
+            assert np.array_equal(buf.action[sl].cpu().numpy(), a)
+            assert np.abs(buf.next_state[sl].cpu().numpy() - ns_ref).max() <= TOL
+            assert np.abs(buf.reward[sl, 0].cpu().numpy() - r_ref).max() <= TOL
+            assert np.array_equal(buf.not_done[sl, 0].cpu().numpy(),
+                                  1.0 - d_ref.astype(np.float32))
+        ptr += n
+        s_ref, _ = ref.harvest()
+    assert abs(reward - total) <= 1e-4 * max(1.0, abs(total))
+    assert np.array_equal(env.flags, ref.flags)
+
+
+def test_tracker_track_filters_and_converts():
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    from tracktolearn_amd.tracking.tracker import TckFile, Tracker, TrkFile
+    from tracktolearn_amd.tractogram import streamline_length
+    torch.manual_seed(2)
+    N, K = 512, 4
+    env, _ = _env(16, N, K, noisy=True, reward=False)
+    alg = SACAuto(env.get_state_size(), 3, '32-32', n_actors=200, rng=None,
+                  device=torch.device(DEV))
+    for fmt in (TrkFile, TckFile):
+        np.random.seed(5)
+        tracker = Tracker(alg, n_actor=200, prob=0.0, min_length=3.0,
+                          max_length=8.0, save_seeds=True)
+        lazy = tracker.track(env, fmt)           # 3 batches: 200, 200, 112
+        items = list(lazy)
+        assert 0 < len(items) < N
+        for it in items:
+            s = it.streamline
+            vox = s / 1.0 - 0.5 if fmt is TrkFile else s
+            assert 3.0 - 1e-6 <= streamline_length(vox) <= 8.0 + 1e-6
+            assert it.data_for_streamline['seeds'].shape == (3,)
+        assert np.array_equal(lazy.affine_to_rasmm, env.affine_vox2rasmm)
