@@ -1,0 +1,100 @@
+"""Entry-point tests.  The reference's own tests are three `--help` smoke
+tests (tests/test_runners.py there); the GPU test below runs BASELINE.json
+config 1 end to end: ttl_track.py on a 32^3 synthetic descoteaux07 order-8
+fODF + WM mask with n_actor = 4096."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ttl_track_help():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'ttl_track.py'),
+                          '--help'], capture_output=True, text=True)
+    assert out.returncode == 0
+    for word in ('in_odf', 'in_seed', 'in_mask', 'out_tractogram', '--n_actor',
+                 '--npv', '--noise', '--binary_stopping_threshold', '--rng_seed',
+                 '--sh_basis', '--compress', '--save_seeds', '--agent',
+                 '--hyperparameters', '--min_length', '--max_length'):
+        assert word in out.stdout
+
+
+def _write_inputs(tmp_path, D=32, order=8):
+    from tracktolearn_amd.io import nifti
+    from tracktolearn_amd.utils.synthetic import synthetic_volumes
+    sh, mask, _ = synthetic_volumes(D, (order + 1) * (order + 2) // 2, peaks=False)
+    aff = np.diag([1.0, 1.0, 1.0, 1.0])
+    aff[:3, 3] = [-16.0, -20.0, 5.0]
+    paths = {k: str(tmp_path / f'{k}.nii.gz') for k in ('odf', 'seed', 'mask')}
+    nifti.save(paths['odf'], sh, aff)
+    nifti.save(paths['seed'], mask, aff)
+    nifti.save(paths['mask'], mask, aff)
+    return paths, aff
+
+
+def _write_agent(tmp_path, input_size, hidden='64-64', n_dirs=4):
+    import torch
+    from tracktolearn_amd.algorithms.shared.offpolicy import SACActorCritic
+    torch.manual_seed(3)
+    agent = SACActorCritic(input_size, 3, hidden, torch.device('cpu'))
+    agent_dir = tmp_path / 'model'
+    agent_dir.mkdir()
+    agent.save(str(agent_dir), 'last_model_state')
+    hp = {'algorithm': 'SACAuto', 'step_size': 0.75, 'voxel_size': '1.0',
+          'max_angle': 30, 'hidden_dims': hidden, 'n_dirs': n_dirs,
+          'target_sh_order': 8.0}
+    hp_path = agent_dir / 'hyperparameters.json'
+    hp_path.write_text(json.dumps(hp))
+    return str(agent_dir), str(hp_path)
+
+
+@pytest.mark.gpu
+def test_ttl_track_config1_end_to_end(tmp_path):
+    from tracktolearn_amd.io import streamlines as sio
+    from tracktolearn_amd.runners import ttl_track
+    from tracktolearn_amd.tractogram import streamline_length
+    paths, aff = _write_inputs(tmp_path)
+    agent_dir, hp = _write_agent(tmp_path, 7 * 45 + 3 * 4)
+    out = str(tmp_path / 'out.trk')
+    argv = [paths['odf'], paths['seed'], paths['mask'], out, '--agent', agent_dir,
+            '--hyperparameters', hp, '--n_actor', '4096', '--npv', '1',
+            '--min_length', '3', '--max_length', '40', '--save_seeds',
+            '--rng_seed', '11']
+    ttl_track.main(argv)
+    tg, header = sio.load_trk(out)
+    assert header['nb_streamlines'] == len(tg) > 100
+    assert np.allclose(header['voxel_to_rasmm'], aff)
+    lo = aff[:3, 3] - 2.0
+    hi = aff[:3, 3] + 32.0 + 2.0
+    for s in tg.streamlines[:500]:
+        assert (s >= lo).all() and (s <= hi).all()
+        assert 3.0 - 1e-3 <= streamline_length(s) <= 40.0 + 1e-3
+    assert tg.data_per_streamline['seeds'].shape == (len(tg), 3)
+    # refuses to overwrite without -f, writes .tck too
+    with pytest.raises(SystemExit):
+        ttl_track.main(argv)
+    out2 = str(tmp_path / 'out.tck')
+    ttl_track.main(argv[:3] + [out2] + argv[4:])
+    tck, fields = sio.load_tck(out2)
+    assert int(fields['count']) == len(tck) == len(tg)
+
+
+def test_from_files_needs_descoteaux_basis(tmp_path):
+    from tracktolearn_amd.datasets.utils import set_sh_order_basis
+    sh = np.zeros((2, 2, 2, 28), np.float32)
+    sh[..., :] = np.arange(28)
+    up = set_sh_order_basis(sh, 'descoteaux07', target_order=8)
+    assert up.shape[-1] == 45 and (up[..., 28:] == 0).all()
+    down = set_sh_order_basis(np.zeros((2, 2, 2, 45), np.float32), 'descoteaux07',
+                              target_order=6)
+    assert down.shape[-1] == 28
+    full = np.tile(np.arange(81, dtype=np.float32), (2, 2, 2, 1))
+    even = set_sh_order_basis(full, 'descoteaux07', target_order=8)
+    assert even.shape[-1] == 45 and even[0, 0, 0, 1] == 4.0   # l=2 starts at index 4
+    with pytest.raises(NotImplementedError):
+        set_sh_order_basis(sh, 'tournier07', target_order=6)

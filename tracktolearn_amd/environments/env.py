@@ -265,10 +265,47 @@ class BaseEnv(object):
 
     @classmethod
     def from_files(cls, env_dto: dict):
-        """env.py:311-347 -- needs a NIfTI reader (nibabel is absent; SURVEY
-        8f.2 is a next row)."""
-        raise NotImplementedError(
-            'from_files needs the NIfTI reader (SURVEY 8f.2, not built yet)')
+        """Environment from NIfTI files, for tracking with a trained agent
+        (env.py:311-347)."""
+        (input_volume, peaks_volume, tracking_mask, seeding_mask) = \
+            BaseEnv._load_files(
+                env_dto['in_odf'], env_dto['in_seed'], env_dto['in_mask'],
+                env_dto['sh_basis'], env_dto['target_sh_order'],
+                need_peaks=bool(env_dto.get('compute_reward')))
+        subj_files = (input_volume, tracking_mask, seeding_mask, peaks_volume,
+                      env_dto.get('reference'))
+        return cls(subj_files, 'testing', env_dto)
+
+    @classmethod
+    def _load_files(cls, signal_file, in_seed, in_mask, sh_basis,
+                    target_sh_order=6, need_peaks=False):
+        """env.py:350-449 without the SH->SF peak extraction: the reference
+        computes peaks here for the alignment reward only, and ``ttl_track.py``
+        runs with ``compute_reward=False``.  Extracting peaks needs
+        dipy's ``repulsion724`` sphere, which cannot be regenerated offline
+        (SURVEY 8f.3)."""
+        from tracktolearn_amd.datasets.utils import (MRIDataVolume,
+                                                     set_sh_order_basis)
+        from tracktolearn_amd.io import nifti
+        if need_peaks:
+            raise NotImplementedError(
+                'peak extraction from SH (reward from files) is not built: '
+                "track with compute_reward=False, as ttl_track.py does")
+        signal = nifti.load(signal_file)
+        zooms = signal.get_zooms()[:3]
+        if not np.allclose(np.mean(zooms), zooms[0], atol=1e-03):
+            print('WARNING: ODF SH file is not isotropic. Tracking cannot be '
+                  'ran robustly. You are entering undefined behavior '
+                  'territory.')
+        data = set_sh_order_basis(signal.get_fdata(dtype=np.float32), sh_basis,
+                                  target_order=target_sh_order,
+                                  target_basis='descoteaux07')
+        seeding = nifti.load(in_seed)
+        tracking = nifti.load(in_mask)
+        signal_volume = MRIDataVolume(data, signal.affine)
+        seeding_volume = MRIDataVolume(seeding.get_fdata(), seeding.affine)
+        tracking_volume = MRIDataVolume(tracking.get_fdata(), tracking.affine)
+        return (signal_volume, None, tracking_volume, seeding_volume)
 
     def get_state_size(self):
         """env.py:451-463."""

@@ -51,14 +51,26 @@ class Tracker(object):
         self.min_length = min_length
         self.max_length = max_length
         self.save_seeds = save_seeds
+        #: one process per GPU: every rank tracks its contiguous shard of each
+        #: seed batch and rank 0 yields the collated streamlines
+        self.rank, self.group_size = 0, 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.group_size = dist.get_rank(), dist.get_world_size()
 
     # ------------------------------------------------------------------ #
-    def _batch_items(self, env, scaled_min, scaled_max):
+    def _batch_arrays(self, env, scaled_min, scaled_max):
         """Streamlines of the finished batch whose arc length (voxels) is in
-        [scaled_min, scaled_max], with their seeds: the filter of
-        tracker.py:120-121 evaluated on the device."""
+        [scaled_min, scaled_max]: the filter of tracker.py:120-121 evaluated
+        on the device.  Returns (packed points (M, 3) f32, kept lengths (k,)
+        i64, seeds (k, 3) f64) as device tensors."""
         n = env._n_total
         from tracktolearn_amd.parallel import kept_lengths, pack_points
+        if n == 0:              # an empty shard of a sharded batch
+            dev = env.device
+            return (torch.zeros((0, 3), dtype=torch.float32, device=dev),
+                    torch.zeros(0, dtype=torch.int64, device=dev),
+                    torch.zeros((0, 3), dtype=torch.float64, device=dev))
         keep_len = kept_lengths(env._buf_lengths[:n], env._buf_flags[:n])
         hist = env._buf_streamlines[:n]
         seg = (hist[:, 1:] - hist[:, :-1]).double()
@@ -69,11 +81,27 @@ class Tracker(object):
         ok = (arc >= scaled_min) & (arc <= scaled_max)
         sel = torch.nonzero(ok).squeeze(1)
         keep_sel = keep_len[sel]
-        points = pack_points(hist[sel], keep_sel).cpu().numpy()
-        offsets = np.concatenate(([0], np.cumsum(keep_sel.cpu().numpy())))
-        sel_np = sel.cpu().numpy()
-        seeds = np.asarray(env.initial_points)[sel_np]
-        for k in range(len(sel_np)):
+        points = pack_points(hist[sel], keep_sel)
+        seeds = torch.from_numpy(np.ascontiguousarray(
+            env.initial_points, dtype=np.float64)).to(hist.device)[sel]
+        return points, keep_sel, seeds
+
+    def _batch_items(self, env, scaled_min, scaled_max):
+        """(streamline, seed) pairs of the finished batch on this process;
+        with a process group, every rank's pairs, on rank 0 only."""
+        points, keep_sel, seeds = self._batch_arrays(env, scaled_min, scaled_max)
+        if self.group_size > 1:
+            from tracktolearn_amd.parallel import all_gather_ragged
+            points = torch.cat(all_gather_ragged(points))
+            keep_sel = torch.cat(all_gather_ragged(keep_sel))
+            seeds = torch.cat(all_gather_ragged(seeds))
+            if self.rank != 0:
+                return
+        points = points.cpu().numpy()
+        keep_np = keep_sel.cpu().numpy()
+        seeds = seeds.cpu().numpy()
+        offsets = np.concatenate(([0], np.cumsum(keep_np)))
+        for k in range(len(keep_np)):
             yield points[offsets[k]:offsets[k + 1]], seeds[k]
 
     def track(self, env, tracts_format):
@@ -93,10 +121,18 @@ class Tracker(object):
             scaled_min_length = self.min_length / vox_size
             scaled_max_length = self.max_length / vox_size
             compress_th_vox = self.compress / vox_size
-            for start in tqdm(range(0, len(env.seeds), batch_size)):
+            for start in tqdm(range(0, len(env.seeds), batch_size),
+                              disable=self.rank != 0):
                 end = min(start + batch_size, len(env.seeds))
-                state = env.reset(start, end)
-                self.alg.validation_episode(state, env, self.prob)
+                if self.group_size > 1:
+                    from tracktolearn_amd.parallel import shard_bounds
+                    lo, hi = shard_bounds(end - start, self.rank, self.group_size)
+                    start, end = start + lo, start + hi
+                if end > start:
+                    state = env.reset(start, end)
+                    self.alg.validation_episode(state, env, self.prob)
+                else:           # an empty shard still joins the collectives
+                    env._n_total = 0
                 for streamline, seed in self._batch_items(
                         env, scaled_min_length, scaled_max_length):
                     if self.compress:
