@@ -98,3 +98,69 @@ def test_from_files_needs_descoteaux_basis(tmp_path):
     assert even.shape[-1] == 45 and even[0, 0, 0, 1] == 4.0   # l=2 starts at index 4
     with pytest.raises(NotImplementedError):
         set_sh_order_basis(sh, 'tournier07', target_order=6)
+
+
+def test_sac_auto_train_help():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'sac_auto_train.py'),
+                          '--help'], capture_output=True, text=True)
+    assert out.returncode == 0
+    for word in ('path', 'experiment', 'id', 'dataset_file', '--n_actor',
+                 '--hidden_dims', '--max_ep', '--log_interval', '--lr', '--gamma',
+                 '--alpha', '--batch_size', '--replay_size', '--oracle_bonus',
+                 '--n_dirs', '--npv', '--theta', '--step_size'):
+        assert word in out.stdout
+
+
+def _write_dataset(path, D=20):
+    from tracktolearn_amd.datasets.SubjectDataset import write_npz_dataset
+    from tracktolearn_amd.utils.synthetic import synthetic_volumes
+    subs = {}
+    for i, sid in enumerate(('sub-a', 'sub-b')):
+        sh, mask, pk = synthetic_volumes(D, 45, seed=50 + i)
+        aff = np.eye(4, dtype=np.float32)
+        subs[sid] = {'input_volume': (sh, aff), 'peaks_volume': (pk, aff),
+                     'tracking_volume': (mask, aff), 'seeding_volume': (mask, aff)}
+    write_npz_dataset(path, {'training': subs})
+
+
+def test_npz_dataset_layout(tmp_path):
+    from tracktolearn_amd.datasets.SubjectDataset import SubjectDataset
+    p = str(tmp_path / 'ds.npz')
+    _write_dataset(p, D=8)
+    ds = SubjectDataset(p, 'training')
+    assert len(ds) == 2 and ds.subjects == ['sub-a', 'sub-b']
+    sid, vol, tracking, seeding, peaks, reference = ds[1]
+    assert sid == 'sub-b' and vol.data.dtype == np.float32
+    assert vol.shape == (8, 8, 8, 45) and peaks.shape == (8, 8, 8, 15)
+    assert vol.affine_vox2rasmm.dtype == np.float32     # float32 affine -> F32 mode
+    assert reference['shape'] == (8, 8, 8)              # anat falls back to tracking
+
+
+@pytest.mark.gpu
+def test_sac_auto_train_config3_smoke(tmp_path):
+    """sac_auto_train.py end to end on a two-subject synthetic dataset: two
+    training episodes with validation, model + hyperparameters + tractogram
+    written (BASELINE config 3 at toy size; no oracle)."""
+    from tracktolearn_amd.trainers import sac_auto_train
+    ds = str(tmp_path / 'ds.npz')
+    _write_dataset(ds)
+    exp = tmp_path / 'exp'
+    sac_auto_train.main([
+        str(exp), 'toy', 'run1', ds, '--max_ep', '2', '--log_interval', '1',
+        '--n_actor', '512', '--hidden_dims', '32-32', '--batch_size', '64',
+        '--replay_size', '20000', '--npv', '1', '--min_length', '2',
+        '--max_length', '20', '--oracle_bonus', '0', '--oracle_checkpoint', '',
+        '--rng_seed', '4'])
+    model = exp / 'model'
+    assert (model / 'last_model_state_actor.pth').exists()
+    assert (model / 'last_model_state_critic.pth').exists()
+    hp = json.loads((model / 'hyperparameters.json').read_text())
+    assert hp['algorithm'] == 'SACAuto' and hp['input_size'] == 7 * 45 + 12
+    assert hp['n_dirs'] == 4 and hp['target_sh_order'] == 8
+    assert list(exp.glob('tractogram_toy_run1_*.trk'))
+    assert (exp / 'plots' / 'train_reward.npy').exists()
+    # the saved agent loads back into the tracking entry point's agent class
+    import torch
+    from tracktolearn_amd.algorithms.shared.offpolicy import SACActorCritic
+    agent = SACActorCritic(hp['input_size'], 3, hp['hidden_dims'], torch.device('cpu'))
+    agent.load(str(model), 'last_model_state')

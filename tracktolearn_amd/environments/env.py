@@ -46,15 +46,16 @@ class BaseEnv(object):
 
     def __init__(self, subject_data, split_id: str, env_dto: dict):
         if type(subject_data) is str:
-            # TrackToLearn/environments/env.py:85-94 reads an HDF5 dataset
-            # through h5py + a torch DataLoader; h5py is absent from this
-            # image (SURVEY 8f.2 "input formats" is a next row).
-            raise NotImplementedError(
-                'HDF5 datasets need h5py, which this image lacks; pass the '
-                'tuple (input_volume, tracking_mask, seeding_mask, peaks, '
-                'reference) of MRIDataVolume objects instead')
-        self.subject_data = subject_data
-        self.split = split_id
+            # env.py:85-94: a dataset file; subjects are visited in a fresh
+            # random order every pass (DataLoader(batch_size=1, shuffle=True))
+            from tracktolearn_amd.datasets.SubjectDataset import SubjectDataset
+            self.dataset_file = subject_data
+            self.split = split_id
+            self.dataset = SubjectDataset(self.dataset_file, self.split)
+            self._subject_order = iter(())
+        else:
+            self.subject_data = subject_data
+            self.split = split_id
 
         self.normalize_obs = False
         self.obs_rms = None
@@ -103,8 +104,20 @@ class BaseEnv(object):
     # ------------------------------------------------------------------ #
     def load_subject(self):
         """Per-subject setup, TrackToLearn/environments/env.py:143-281."""
-        (input_volume, tracking_mask, seeding_mask, peaks,
-         reference) = self.subject_data
+        if hasattr(self, 'dataset_file'):
+            if hasattr(self, 'subject_id') and len(self.dataset) == 1:
+                return
+            try:
+                index = next(self._subject_order)
+            except StopIteration:
+                self._subject_order = iter(
+                    torch.randperm(len(self.dataset)).tolist())
+                index = next(self._subject_order)
+            (self.subject_id, input_volume, tracking_mask, seeding_mask,
+             peaks, reference) = self.dataset[index]
+        else:
+            (input_volume, tracking_mask, seeding_mask, peaks,
+             reference) = self.subject_data
 
         self.affine_vox2rasmm = input_volume.affine_vox2rasmm
         self.affine_rasmm2vox = np.linalg.inv(self.affine_vox2rasmm)
