@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Learner-side timings for BASELINE config 3 (SAC, hidden 1024-1024,
+n_actor = 65536, 96^3 x 45 volume, K = 4): SACAuto.update alone, replay
+add/sample, and the full training step (policy -> env step -> replay add ->
+sample -> update -> harvest).  Auxiliary to bench.py (which measures
+config 2, the headline metric)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timeit(fn, n, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--hidden', default='1024-1024')
+    ap.add_argument('--n_actor', type=int, default=65536)
+    ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--graph', action='store_true')
+    args = ap.parse_args()
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    from tracktolearn_amd.environments import TrackingEnvironment
+    from tracktolearn_amd.utils.synthetic import (synthetic_seeds,
+                                                  synthetic_subject)
+    dev = torch.device('cuda:0')
+    subject = synthetic_subject(96, 45, seed=1234, peaks=True)
+    dto = dict(n_dirs=4, theta=30.0, npv=1, binary_stopping_threshold=0.1,
+               step_size=0.75, min_length=20.0, max_length=200.0,
+               compute_reward=True, alignment_weighting=1.0, oracle_bonus=0.0,
+               rng=np.random.RandomState(0), device=dev, target_sh_order=8)
+    env = TrackingEnvironment(subject, 'training', dto)
+    env.seeds = synthetic_seeds(subject[1].data, args.n_actor, seed=1)
+    W = env.get_state_size()
+    torch.manual_seed(0)
+    alg = SACAuto(W, 3, args.hidden, n_actors=args.n_actor, batch_size=args.batch,
+                  replay_size=int(1e6), rng=None, device=dev)
+    if args.graph:
+        alg.enable_graph()
+    out = {'W': W, 'hidden': args.hidden, 'n_actor': args.n_actor,
+           'batch': args.batch, 'graph': args.graph}
+    # fill the ring with a few env steps
+    state = env.reset(0, args.n_actor)
+    for _ in range(4):
+        if state.shape[0] == 0:
+            state = env.reset(0, args.n_actor)
+        a = alg.sample_action(state)
+        ns, r, d, info = env.step_device(a)
+        alg.replay_buffer.add_partitioned(state, a, ns, info['row_dest'], r, d)
+        state, _ = env.harvest()
+    batch = alg.replay_buffer.sample(args.batch)
+    out['update_ms'] = timeit(lambda: alg.update(batch), 30)
+    out['sample_ms'] = timeit(lambda: alg.replay_buffer.sample(args.batch), 30)
+    alg.start_timesteps = 0
+    # full training steps on a fresh episode
+    state = env.reset(0, args.n_actor)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_units = 0
+    steps = 12
+    for _ in range(steps):
+        if state.shape[0] == 0:          # a random policy ends episodes fast
+            state = env.reset(0, args.n_actor)
+        with torch.no_grad():
+            a = alg.sample_action(state)
+        n = a.shape[0]
+        ns, r, d, info = env.step_device(a)
+        alg.replay_buffer.add_partitioned(state, a, ns, info['row_dest'], r, d)
+        alg.update(alg.replay_buffer.sample(args.batch))
+        state, _ = env.harvest()
+        n_units += n
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['train_step_ms'] = dt / steps * 1e3
+    out['train_streamline_steps_per_s'] = n_units / dt
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -23,11 +23,13 @@ class SACAuto(SAC):
         self.start_timesteps = 80000
         self.agent_freq = 1
 
-    def update(self, batch):
+    def _optimizers(self):
+        return [self.alpha_optimizer, self.actor_optimizer, self.critic_optimizer]
+
+    def _update_impl(self, batch):
         """sac_auto.py:139-250: temperature, actor, critic steps in that
         order, then Polyak averaging of critic and actor targets.  Returns an
         empty dict, as the reference does (all its entries are commented)."""
-        self.total_it += 1
         state = batch[0]
         pi, logp_pi = self.agent.act(state, probabilistic=1.0,
                                      eps=self._eps(batch[1]))
