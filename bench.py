@@ -157,11 +157,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('launch with torch.distributed.run for --gpus > 1')
+    # rehearsal on a 1-GPU box: TTL_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and TTL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks
+    # on one device); the driver's real runs use neither
+    if os.environ.get('TTL_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('TTL_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -207,8 +216,9 @@ def main():
         torch.cuda.synchronize()
         collate_ms = (time.perf_counter() - t1) * 1e3
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    units = torch.tensor([float(n_units)], dtype=torch.float64, device=device)
+    red_dev = device if backend == 'nccl' else 'cpu'
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    units = torch.tensor([float(n_units)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(units, op=dist.ReduceOp.SUM)

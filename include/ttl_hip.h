@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTL_ABI_VERSION 2
+#define TTL_ABI_VERSION 3
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -57,6 +57,7 @@ extern "C" {
 #define TTL_FLAG_MASK 1
 #define TTL_FLAG_LENGTH 2
 #define TTL_FLAG_CURVATURE 4
+#define TTL_FLAG_ORACLE 64
 
 /* Row order of the state rows written by ttl_env_step():
  *   ORDER_ACTIVE    row i of the output = i-th active streamline (the order
@@ -158,6 +159,22 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
                  int32_t n_active, int32_t order, float *state_out,
                  int64_t state_pitch, double *reward_out, uint8_t *done_out,
                  int32_t *host_counts, void *hip_stream);
+
+/* The same step in two halves, for stopping criteria evaluated outside the
+ * library (OracleStoppingCriterion, stopping_criteria.py:85-154, needs the new
+ * points and a transformer forward):
+ *   ttl_env_step_begin  actions -> new points, LENGTH/CURVATURE/MASK
+ *                       decisions, reward, done_out;
+ *   (caller computes extra_flags[n_active] u8, e.g. TTL_FLAG_ORACLE per row)
+ *   ttl_env_step_end    ORs extra_flags (may be NULL) into flags / dones /
+ *                       done_out, compacts, writes the state rows.
+ * ttl_env_step() == begin + end(NULL). */
+int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
+                       int32_t n_active, double *reward_out, uint8_t *done_out,
+                       void *hip_stream);
+int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
+                     float *state_out, int64_t state_pitch, int32_t *host_counts,
+                     void *hip_stream);
 
 /* Blocks the calling host thread until the host_counts of the last
  * ttl_env_step() have landed (not until the step has finished). */

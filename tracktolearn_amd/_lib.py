@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MODE_F32 = 0
 MODE_F64DIR = 1
 MODE_F32NORM = 2
@@ -69,6 +69,12 @@ SYMBOLS = {
     'ttl_env_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttl_env_step_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    'ttl_env_step_end': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p]),
     'ttl_env_wait_counts': (C.c_int, [C.c_void_p]),
     'ttl_env_harvest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_void_p]),

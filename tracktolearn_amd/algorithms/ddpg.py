@@ -90,7 +90,13 @@ class DDPG(RLAlgorithm):
             if reward is None:
                 reward = torch.zeros(n, dtype=torch.float64, device=self.device)
             else:
-                factor_means.append(reward.mean())
+                term = getattr(env, '_last_oracle_term', None)
+                if term is None:
+                    factor_means.append(torch.stack(
+                        [reward.mean(), torch.zeros_like(reward[0])]))
+                else:
+                    factor_means.append(torch.stack(
+                        [(reward - term).mean(), term.mean()]))
             # n transitions, as if n agents were gathering them (ddpg.py:194-207)
             self.replay_buffer.add_partitioned(
                 state, action, next_state, info['row_dest'], reward, done)
@@ -104,10 +110,9 @@ class DDPG(RLAlgorithm):
             episode_length += 1
         running_reward_factors = defaultdict(list)
         if factor_means:
-            peaks = torch.stack(factor_means).cpu().numpy()
-            running_reward_factors = {
-                'peaks_reward': list(peaks),
-                'oracle_reward': [np.float64(0.0)] * len(peaks)}
+            means = torch.stack(factor_means).cpu().numpy()
+            running_reward_factors = {'peaks_reward': list(means[:, 0]),
+                                      'oracle_reward': list(means[:, 1])}
         return (float(reward_sum), running_losses, episode_length,
                 running_reward_factors)
 

@@ -237,6 +237,31 @@ __device__ __forceinline__ int stopping_bits(
     return bits;
 }
 
+// Stable survivor ranks of one 256-thread block: 64-bit ballot per wavefront,
+// popcount of the lanes below, then the 4 wave totals through LDS.  Writes
+// rank[i] (survivors before row i inside the block) and the block's count.
+__device__ __forceinline__ void block_survivor_ranks(const EnvParams &P, int i,
+                                                     bool active, bool keep) {
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int below = __popcll(m & ((1ull << lane) - 1ull));
+    __shared__ int wave_total[BLOCK / 64];
+    if (lane == 0) wave_total[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w)
+        if (w < wave) before += wave_total[w];
+    if (active) P.rank[i] = before + below;
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) tot += wave_total[w];
+        P.block_counts[blockIdx.x] = tot;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_advance: one thread per active streamline.
 // ---------------------------------------------------------------------------
@@ -379,27 +404,35 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
         P.stop[i] = stop ? 1 : 0;
     }
 
-    // wave-ballot survivor ranks (stable): 64-bit ballot per wavefront,
-    // popcount of the lanes below, then the 4 wave totals through LDS.
-    const bool keep = active && !stop;
-    const unsigned long long m = __ballot(keep);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int below = __popcll(m & ((1ull << lane) - 1ull));
-    __shared__ int wave_total[BLOCK / 64];
-    if (lane == 0) wave_total[wave] = __popcll(m);
-    __syncthreads();
-    int before = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w)
-        if (w < wave) before += wave_total[w];
-    if (active) P.rank[i] = before + below;
-    if (threadIdx.x == 0) {
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) tot += wave_total[w];
-        P.block_counts[blockIdx.x] = tot;
+    block_survivor_ranks(P, i, active, active && !stop);
+}
+
+// ---------------------------------------------------------------------------
+// k_restop: OR externally computed stopping bits (the oracle criterion,
+// stopping_criteria.py:85-154, evaluated by the host-side oracle between
+// k_advance and k_prefix) into the step's decisions and redo the ranks.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_restop(EnvParams P,
+                                                  const int *__restrict__ idx,
+                                                  const uint8_t *__restrict__ extra,
+                                                  int n_active,
+                                                  uint8_t *__restrict__ done_out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < n_active;
+    bool stop = false;
+    if (active) {
+        stop = P.stop[i] != 0;
+        const int bits = extra[i];
+        if (bits) {
+            const int g = idx[i];
+            P.flags[g] = (stop ? P.flags[g] : 0) | bits;
+            P.dones[g] = 1;
+            P.stop[i] = 1;
+            done_out[i] = 1;
+            stop = true;
+        }
     }
+    block_survivor_ranks(P, i, active, active && !stop);
 }
 
 // ---------------------------------------------------------------------------
@@ -884,9 +917,10 @@ struct ttl_env {
     int length;      // points per active streamline (reference: self.length)
     int n_active;    // rows of the current continue_idx
     int cur;         // 0: idx_a is continue_idx, 1: idx_b
-    int stepped;     // a step is waiting for its harvest
+    int stepped;     // 0: idle, 2: step begun (advanced), 1: step done, awaiting harvest
     int last_order;
     int last_n;      // n_active of the pending step
+    uint8_t *last_done;  // done_out of the pending step (k_restop updates it)
     // optional per-kernel timing with HIP events on the caller's stream
     int state_kernel; // 0: k_state (all 56 corner fetches), else k_state_dd
     hipStream_t side;      // carries the early device->host copy of the counts
@@ -1022,6 +1056,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->stepped = 0;
     e->last_order = TTL_ORDER_ACTIVE;
     e->last_n = 0;
+    e->last_done = nullptr;
     e->state_kernel = 4;
     if (const char *v = getenv("TTL_STATE_KERNEL")) e->state_kernel = atoi(v);
     e->side = nullptr;
@@ -1163,30 +1198,23 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n, float *state_out,
     return launch_state(env, nullptr, nullptr, n, 1, state_out, state_pitch, s);
 }
 
-int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
-                 int32_t n_active, int32_t order, float *state_out,
-                 int64_t state_pitch, double *reward_out, uint8_t *done_out,
-                 int32_t *host_counts, void *hip_stream) {
-    if (!env || !actions || !state_out || !done_out)
+int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
+                       int32_t n_active, double *reward_out, uint8_t *done_out,
+                       void *hip_stream) {
+    if (!env || !actions || !done_out)
         return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
     if (env->length < 1) return fail(TTL_ERR_STATE, "ttl_env_step: reset first");
     if (env->stepped) return fail(TTL_ERR_STATE, "ttl_env_step: harvest the previous step first");
     if (n_active < 1 || n_active > env->n_active)
         return fail(TTL_ERR_INVALID, "ttl_env_step: n_active=%d outside [1, %d]",
                     n_active, env->n_active);
-    if (order != TTL_ORDER_ACTIVE && order != TTL_ORDER_PARTITION)
-        return fail(TTL_ERR_INVALID, "ttl_env_step: bad order %d", order);
     const ttl_env_desc &d = env->d;
     if (env->length > d.max_nb_steps)
         return fail(TTL_ERR_STATE, "ttl_env_step: streamline history is full");
-    const int64_t width = 7LL * d.n_coef + 3LL * d.n_dirs;
-    if (state_pitch < width)
-        return fail(TTL_ERR_INVALID, "ttl_env_step: state_pitch too small");
     if (noise && d.mode != TTL_MODE_F64DIR)
         return fail(TTL_ERR_INVALID, "ttl_env_step: noise needs TTL_MODE_F64DIR");
     hipStream_t s = (hipStream_t)hip_stream;
     const int *idx = env->cur ? d.idx_b : d.idx_a;
-    int *idx_next = env->cur ? d.idx_a : d.idx_b;
     const int L = env->length;
     const int nb = (n_active + BLOCK - 1) / BLOCK;
     prof_mark(env, 0, 0, s);
@@ -1199,9 +1227,40 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
 #undef TTL_LAUNCH_ADVANCE
     prof_mark(env, 0, 1, s);
     HIP_TRY(hipGetLastError());
+    env->length = L + 1;
+    env->stepped = 2;          // advanced, not yet committed
+    env->last_n = n_active;
+    env->last_done = done_out;
+    return TTL_OK;
+}
+
+int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
+                     float *state_out, int64_t state_pitch, int32_t *host_counts,
+                     void *hip_stream) {
+    if (!env || !state_out)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
+    if (env->stepped != 2)
+        return fail(TTL_ERR_STATE, "ttl_env_step_end: call ttl_env_step_begin first");
+    if (order != TTL_ORDER_ACTIVE && order != TTL_ORDER_PARTITION)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: bad order %d", order);
+    const ttl_env_desc &d = env->d;
+    const int64_t width = 7LL * d.n_coef + 3LL * d.n_dirs;
+    if (state_pitch < width)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: state_pitch too small");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int *idx = env->cur ? d.idx_b : d.idx_a;
+    int *idx_next = env->cur ? d.idx_a : d.idx_b;
+    const int n_active = env->last_n;
+    const int n_pts = env->length;
+    const int nb = (n_active + BLOCK - 1) / BLOCK;
+    if (extra_flags) {
+        hipLaunchKernelGGL(k_restop, dim3(nb), dim3(BLOCK), 0, s, env->P, idx,
+                           extra_flags, n_active, env->last_done);
+        HIP_TRY(hipGetLastError());
+    }
     prof_mark(env, 1, 0, s);
     hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
-                       n_active, nb, order, L + 1);
+                       n_active, nb, order, n_pts);
     prof_mark(env, 1, 1, s);
     HIP_TRY(hipGetLastError());
     if (host_counts) {
@@ -1220,21 +1279,38 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
         HIP_TRY(hipEventRecord(env->ev_counts, env->side));
         env->counts_pending = 1;
     }
-    env->length = L + 1;
     env->stepped = 1;
     env->last_order = order;
-    env->last_n = n_active;
     prof_mark(env, 2, 0, s);
-    const int rc = launch_state(env, idx, env->P.row_dest, n_active, L + 1,
+    const int rc = launch_state(env, idx, env->P.row_dest, n_active, n_pts,
                                 state_out, state_pitch, s);
     prof_mark(env, 2, 1, s);
     return rc;
 }
 
+int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
+                 int32_t n_active, int32_t order, float *state_out,
+                 int64_t state_pitch, double *reward_out, uint8_t *done_out,
+                 int32_t *host_counts, void *hip_stream) {
+    if (!state_out) return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
+    if (order != TTL_ORDER_ACTIVE && order != TTL_ORDER_PARTITION)
+        return fail(TTL_ERR_INVALID, "ttl_env_step: bad order %d", order);
+    if (env) {
+        const int64_t width = 7LL * env->d.n_coef + 3LL * env->d.n_dirs;
+        if (state_pitch < width)
+            return fail(TTL_ERR_INVALID, "ttl_env_step: state_pitch too small");
+    }
+    const int rc = ttl_env_step_begin(env, actions, noise, n_active, reward_out,
+                                      done_out, hip_stream);
+    if (rc != TTL_OK) return rc;
+    return ttl_env_step_end(env, nullptr, order, state_out, state_pitch,
+                            host_counts, hip_stream);
+}
+
 int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
                     int64_t state_pitch, void *hip_stream) {
     if (!env) return fail(TTL_ERR_INVALID, "ttl_env_harvest: null handle");
-    if (!env->stepped) return fail(TTL_ERR_STATE, "ttl_env_harvest: no step to harvest");
+    if (env->stepped != 1) return fail(TTL_ERR_STATE, "ttl_env_harvest: no finished step to harvest");
     const ttl_env_desc &d = env->d;
     hipStream_t s = (hipStream_t)hip_stream;
     const int *idx = env->cur ? d.idx_b : d.idx_a;

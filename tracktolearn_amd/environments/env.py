@@ -88,13 +88,19 @@ class BaseEnv(object):
             raise RuntimeError(
                 'tracktolearn_amd environments run on an MI355X only '
                 f"(env_dto['device']={self.device}); there is no CPU fallback")
-        if self.oracle_stopping_criterion or (
-                self.compute_reward and self.oracle_bonus and
-                self.oracle_bonus > 0):
-            raise NotImplementedError(
-                'oracle reward / oracle stopping (SURVEY 8f.4) are not built '
-                'yet; run with oracle_bonus=0 and '
-                'oracle_stopping_criterion=False')
+        #: keep the reference's tail-batch quirk of OracleSingleton.predict
+        #: unless told otherwise
+        self.oracle_drop_tail = bool(env_dto.get('oracle_drop_tail', True))
+        self._use_oracle_reward = bool(
+            self.compute_reward and self.oracle_bonus and self.oracle_bonus > 0)
+        self._use_oracle_stopping = bool(
+            self.oracle_checkpoint and self.oracle_stopping_criterion)
+        if self._use_oracle_reward and not self.oracle_checkpoint:
+            # the reference only fails later, with `w * None`, once a
+            # streamline longer than min_nb_steps is done
+            raise ValueError(
+                'oracle_bonus > 0 needs an oracle_checkpoint; use '
+                "oracle_bonus=0 / --oracle_bonus 0 to train without the oracle")
 
         self._lib = _lib.load()
         self._handle = None
@@ -194,6 +200,28 @@ class BaseEnv(object):
             self._mode = _lib.MODE_F32
         self._curv_dot_max, self._curv_enabled = \
             curvature_dot_threshold(self.theta)
+
+        # --- oracle (reward.py / oracle_reward.py / stopping_criteria.py) - #
+        self._oracle = None
+        if self._use_oracle_reward or self._use_oracle_stopping:
+            from tracktolearn_amd.oracles.oracle import OracleSingleton
+            self._oracle = OracleSingleton(self.oracle_checkpoint, self.device)
+            self._oracle.drop_tail = self.oracle_drop_tail
+            # voxel space of the tracked volume -> voxel space of the
+            # reference anatomy (oracle_reward.py:82-90: vox -> rasmm -> the
+            # reference's vox, corner origin; the shift drops out of the
+            # segment vectors the oracle consumes)
+            ref_affine = None
+            if isinstance(reference, dict):
+                ref_affine = reference.get('affine')
+            elif hasattr(reference, 'affine'):
+                ref_affine = reference.affine
+            lin = np.eye(3)
+            if ref_affine is not None:
+                lin = np.linalg.inv(np.asarray(ref_affine, np.float64))[:3, :3] @ \
+                    np.asarray(self.affine_vox2rasmm, np.float64)[:3, :3]
+            self._oracle_lin = None if np.allclose(lin, np.eye(3)) else \
+                torch.from_numpy(lin.T.astype(np.float32)).to(self.device)
 
         self._destroy_handle()
         self._n_max = 0

@@ -126,17 +126,74 @@ class TrackingEnvironment(BaseEnv):
         reward = None
         if self.compute_reward:
             reward = torch.empty(n, dtype=torch.float64, device=self.device)
-        _lib.check(self._lib.ttl_env_step(
-            self._handle, a.data_ptr(),
-            noise.data_ptr() if noise is not None else None, n, order,
-            state.data_ptr(), self._state_width,
-            reward.data_ptr() if reward is not None else None,
-            done.data_ptr(), self._host_counts.data_ptr(), self._stream()),
-            'ttl_env_step')
+        noise_ptr = noise.data_ptr() if noise is not None else None
+        reward_ptr = reward.data_ptr() if reward is not None else None
+        if not self._use_oracle_stopping:
+            _lib.check(self._lib.ttl_env_step(
+                self._handle, a.data_ptr(), noise_ptr, n, order,
+                state.data_ptr(), self._state_width, reward_ptr,
+                done.data_ptr(), self._host_counts.data_ptr(), self._stream()),
+                'ttl_env_step')
+        else:
+            # the oracle criterion sits between the point update and the
+            # compaction (criteria order LENGTH, CURVATURE, ORACLE, MASK;
+            # env.py:233-260 -- the flags are OR-ed, so the order is moot)
+            _lib.check(self._lib.ttl_env_step_begin(
+                self._handle, a.data_ptr(), noise_ptr, n, reward_ptr,
+                done.data_ptr(), self._stream()), 'ttl_env_step_begin')
+            extra = self._oracle_stopping_flags(n, self.length + 1)
+            _lib.check(self._lib.ttl_env_step_end(
+                self._handle, extra.data_ptr() if extra is not None else None,
+                order, state.data_ptr(), self._state_width,
+                self._host_counts.data_ptr(), self._stream()),
+                'ttl_env_step_end')
+            self._keep_alive = extra
+        self._last_oracle_term = None
+        if self._use_oracle_reward:
+            self._last_oracle_term = self._oracle_reward(
+                n, self.length + 1, done, reward)
         self.length += 1
         self._pending = dict(order=order, state=state, n=n, done=done,
                              keep=(a, noise))
         return state, reward, done
+
+    # -- oracle criterion / reward: torch ops between the library calls ----- #
+    def _oracle_points(self, rows, n_points):
+        """Histories (len(rows), n_points, 3) of the given active rows, in the
+        reference anatomy's voxel space (oracle_reward.py:82-90)."""
+        g = self._idx_view(self._n_active)[rows].long() if rows is not None \
+            else self._idx_view(self._n_active).long()
+        pts = self._buf_streamlines[g, :n_points]
+        if self._oracle_lin is not None:
+            pts = pts @ self._oracle_lin
+        return pts
+
+    def _oracle_stopping_flags(self, n, n_points):
+        """OracleStoppingCriterion.__call__ (stopping_criteria.py:115-154) on
+        every active streamline once they have more than 5 * min_nb_steps
+        points: ORACLE bit where the score is < 0.5.  None before that."""
+        if not n_points > self.min_nb_steps * 5:
+            return None
+        scores = self._oracle.predict(self._oracle_points(None, n_points))
+        from tracktolearn_amd.environments.stopping_criteria import StoppingFlags
+        return (scores < 0.5).to(torch.uint8) * \
+            StoppingFlags.STOPPING_ORACLE.value
+
+    def _oracle_reward(self, n, n_points, done, reward):
+        """OracleReward.__call__ (oracle_reward.py:70-93): +oracle_bonus for the
+        streamlines that stopped in this step with a score > 0.5, once the
+        streamlines are longer than min_nb_steps.  Adds into ``reward`` and
+        returns the oracle term (or None when nothing was scored)."""
+        if not n_points > self.min_nb_steps:
+            return None
+        rows = torch.nonzero(done).squeeze(1)         # host sync: count of dones
+        if rows.numel() == 0:
+            return None
+        scores = self._oracle.predict(self._oracle_points(rows, n_points))
+        term = torch.zeros(n, dtype=torch.float64, device=self.device)
+        term[rows] = (scores > 0.5).double() * float(self.oracle_bonus)
+        reward += term
+        return term
 
     def step(self, actions):
         """Apply actions, grow every active streamline by one step, test the
@@ -156,8 +213,11 @@ class TrackingEnvironment(BaseEnv):
         if reward is not None:
             reward_np = reward.to('cpu').numpy()
             # reward.py:73-75: mean of each weighted factor
-            reward_info = {'peaks_reward': np.mean(reward_np),
-                           'oracle_reward': np.float64(0.0)}
+            oracle_np = np.zeros_like(reward_np)
+            if self._last_oracle_term is not None:
+                oracle_np = self._last_oracle_term.to('cpu').numpy()
+            reward_info = {'peaks_reward': np.mean(reward_np - oracle_np),
+                           'oracle_reward': np.mean(oracle_np)}
         else:
             reward_np = np.zeros(self._n_total)
         info = _StepInfo(self, self._pending['n'], reward_info)
