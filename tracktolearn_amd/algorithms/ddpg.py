@@ -66,12 +66,17 @@ class DDPG(RLAlgorithm):
             return a + torch.randn_like(a) * (self.max_action * self.action_std)
 
     def _polyak(self):
-        """target <- tau * online + (1 - tau) * target, critic then actor."""
+        """target <- tau * online + (1 - tau) * target, critic then actor
+        (ddpg.py:300-317).  Same three roundings per element as the
+        reference's per-parameter loop, issued as multi-tensor kernels."""
         with torch.no_grad():
             for net, tgt in ((self.agent.critic, self.target.critic),
                              (self.agent.actor, self.target.actor)):
-                for p, tp in zip(net.parameters(), tgt.parameters()):
-                    tp.data.copy_(self.tau * p.data + (1 - self.tau) * tp.data)
+                online = [p.data for p in net.parameters()]
+                target = [p.data for p in tgt.parameters()]
+                scaled = torch._foreach_mul(online, self.tau)
+                torch._foreach_mul_(target, 1 - self.tau)
+                torch._foreach_add_(target, scaled)
 
     def _episode(self, initial_state, env):
         """Track one batch of streamlines to exhaustion while learning

@@ -37,6 +37,14 @@ class OffPolicyReplayBuffer(object):
     def _slots(self, n):
         return (torch.arange(n, device=self.device) + self.ptr) % self.max_size
 
+    def _put(self, ring, ind, rows):
+        """ring[ind] = rows; a plain slice copy when the slots do not wrap."""
+        n = len(rows)
+        if self.ptr + n <= self.max_size:
+            ring[self.ptr:self.ptr + n] = rows
+        else:
+            ring[ind] = rows
+
     def _advance(self, n):
         self.ptr = (self.ptr + n) % self.max_size
         self.size = min(self.size + n, self.max_size)
@@ -46,11 +54,11 @@ class OffPolicyReplayBuffer(object):
         ``done`` are (n, 1) or (n,)."""
         n = len(state)
         ind = self._slots(n)
-        self.state[ind] = self._dev(state)
-        self.action[ind] = self._dev(action)
-        self.next_state[ind] = self._dev(next_state)
-        self.reward[ind] = self._dev(reward).reshape(n, 1)
-        self.not_done[ind] = 1. - self._dev(done).reshape(n, 1)
+        self._put(self.state, ind, self._dev(state))
+        self._put(self.action, ind, self._dev(action))
+        self._put(self.next_state, ind, self._dev(next_state))
+        self._put(self.reward, ind, self._dev(reward).reshape(n, 1))
+        self._put(self.not_done, ind, 1. - self._dev(done).reshape(n, 1))
         self._advance(n)
 
     def add_partitioned(self, state, action, next_state, row_dest, reward, done):
@@ -60,13 +68,13 @@ class OffPolicyReplayBuffer(object):
         transitions, no intermediate re-ordering copy."""
         n = len(state)
         ind = self._slots(n)
-        self.state[ind] = self._dev(state)
-        self.action[ind] = self._dev(action)
+        self._put(self.state, ind, self._dev(state))
+        self._put(self.action, ind, self._dev(action))
         slot_of_row = torch.empty_like(ind)
         slot_of_row[row_dest.long()] = ind
         self.next_state[slot_of_row] = next_state
-        self.reward[ind] = self._dev(reward).reshape(n, 1)
-        self.not_done[ind] = 1. - self._dev(done).reshape(n, 1)
+        self._put(self.reward, ind, self._dev(reward).reshape(n, 1))
+        self._put(self.not_done, ind, 1. - self._dev(done).reshape(n, 1))
         self._advance(n)
 
     def __len__(self):
