@@ -320,18 +320,14 @@ class BaseEnv(object):
     @classmethod
     def _load_files(cls, signal_file, in_seed, in_mask, sh_basis,
                     target_sh_order=6, need_peaks=False):
-        """env.py:350-449 without the SH->SF peak extraction: the reference
-        computes peaks here for the alignment reward only, and ``ttl_track.py``
-        runs with ``compute_reward=False``.  Extracting peaks needs
-        dipy's ``repulsion724`` sphere, which cannot be regenerated offline
-        (SURVEY 8f.3)."""
+        """env.py:350-449.  The reference always extracts fODF peaks here, but
+        only the alignment reward consumes them and ``ttl_track.py`` runs with
+        ``compute_reward=False``, so they are computed on demand
+        (``need_peaks``), on the GPU (tracktolearn_amd/reconst/peaks.py; own
+        sphere -> parity unpinned)."""
         from tracktolearn_amd.datasets.utils import (MRIDataVolume,
                                                      set_sh_order_basis)
         from tracktolearn_amd.io import nifti
-        if need_peaks:
-            raise NotImplementedError(
-                'peak extraction from SH (reward from files) is not built: '
-                "track with compute_reward=False, as ttl_track.py does")
         signal = nifti.load(signal_file)
         zooms = signal.get_zooms()[:3]
         if not np.allclose(np.mean(zooms), zooms[0], atol=1e-03):
@@ -344,9 +340,17 @@ class BaseEnv(object):
         seeding = nifti.load(in_seed)
         tracking = nifti.load(in_mask)
         signal_volume = MRIDataVolume(data, signal.affine)
+        peaks_volume = None
+        if need_peaks:
+            from tracktolearn_amd.reconst.peaks import peaks_from_sh
+            from tracktolearn_amd.utils.torch_utils import get_device
+            sh_dev = torch.from_numpy(np.ascontiguousarray(
+                data, dtype=np.float32)).to(get_device())
+            peaks_volume = MRIDataVolume(
+                peaks_from_sh(sh_dev).cpu().numpy(), signal.affine)
         seeding_volume = MRIDataVolume(seeding.get_fdata(), seeding.affine)
         tracking_volume = MRIDataVolume(tracking.get_fdata(), tracking.affine)
-        return (signal_volume, None, tracking_volume, seeding_volume)
+        return (signal_volume, peaks_volume, tracking_volume, seeding_volume)
 
     def get_state_size(self):
         """env.py:451-463."""
