@@ -130,3 +130,24 @@ def test_tractogram_container():
     A[:3, 3] = 1
     a.apply_affine(A)
     assert np.allclose(a.streamlines[1], 3.0)
+
+
+def test_library_binds_to_torchs_hip_runtime():
+    """libttl_hip.so must share the HIP runtime PyTorch loaded (one runtime per
+    process), whatever the import order was: tracktolearn_amd._lib imports
+    torch before it dlopens the library."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from tracktolearn_amd import _lib\n"       # before any `import torch`
+        "_lib.load()\n"
+        "import torch\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "libs = sorted({l.split()[-1] for l in maps.splitlines() "
+        "if 'libamdhip64' in l})\n"
+        "print(len(libs), libs)\n") % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True,
+                         text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == '1', out.stdout

@@ -7,6 +7,14 @@ There is no CPU fallback: if the shared library is missing or does not load,
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME
+# libamdhip64.so.7).  It must be in the process BEFORE libttl_hip.so is
+# dlopen-ed so that the dynamic loader binds our NEEDED libamdhip64.so.7 to
+# that same copy; loaded the other way round, /opt/rocm's runtime comes in
+# first, torch then loads its own as a second runtime, and our kernels run on
+# a runtime that has no device ("no ROCm-capable device is detected").
+import torch  # noqa: F401  (keep above the CDLL below)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
