@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTL_ABI_VERSION 3
+#define TTL_ABI_VERSION 4
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -134,9 +134,15 @@ void ttl_env_destroy(ttl_env *env);
 /* TrackingEnvironment.reset / nreset (tracking_env.py:91-133 / 47-89):
  * n seeds (float32 [n][3], voxel space) become streamlines 0..n-1 of one
  * point; flags 0, lengths 1, dones 0, continue_idx = arange(n); writes the
- * first state rows ([n][state_pitch] f32, state_pitch >= 7*C + 3*K). */
+ * first state rows ([n][state_pitch] f32, state_pitch >= 7*C + 3*K).
+ * processing_order (device int32 [n], a permutation of 0..n-1, or NULL) does
+ * not change any result: it only chooses which streamlines one workgroup of
+ * the state gather handles together.  Passing the seeds sorted by spatial
+ * brick lets neighbouring workgroups share voxels through L2; the library
+ * keeps the order compacted as streamlines stop. */
 int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
-                  float *state_out, int64_t state_pitch, void *hip_stream);
+                  const int32_t *processing_order, float *state_out,
+                  int64_t state_pitch, void *hip_stream);
 
 /* TrackingEnvironment.step (tracking_env.py:135-221) for the n_active
  * streamlines of continue_idx (n_active must equal the count the last

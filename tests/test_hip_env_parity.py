@@ -181,13 +181,18 @@ def _scripted(rng, state_np, n_sh, step, wobble):
     (False, np.float32, 4, False, 0.75, '0'),   # the 56-fetch state kernel
     (False, np.float32, 4, False, 1.25, None),  # radius >= 1 voxel -> 56-fetch kernel
     (False, np.float32, 4, False, 0.30, None),  # small radius: few outer slices
+    (False, np.float32, 4, True, 0.75, 'sorted'),   # brick-sorted processing order
+    (True, np.float64, 100, False, 0.75, 'sorted'),
 ])
 def test_random_episode_against_oracle(noisy, affine, K, reward, step_mm, kernel,
                                        monkeypatch):
     """4096 streamlines on a 24^3 volume, scripted actions, run to exhaustion:
     HIP env vs CPU oracle step by step."""
     from oracle import env_oracle as orc
-    if kernel is not None:
+    if kernel == 'sorted':
+        from tracktolearn_amd.environments import TrackingEnvironment
+        monkeypatch.setattr(TrackingEnvironment, 'SPATIAL_ORDER_MIN', 1)
+    elif kernel is not None:
         monkeypatch.setenv('TTL_STATE_KERNEL', kernel)
     D, N = 24, 4096
     sh, mask, pk = synthetic_subject(D)

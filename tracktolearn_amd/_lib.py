@@ -18,7 +18,7 @@ import torch  # noqa: F401  (keep above the CDLL below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MODE_F32 = 0
 MODE_F64DIR = 1
 MODE_F32NORM = 2
@@ -73,7 +73,7 @@ SYMBOLS = {
     'ttl_env_create': (C.c_int, [C.POINTER(EnvDesc), C.POINTER(C.c_void_p)]),
     'ttl_env_destroy': (None, [C.c_void_p]),
     'ttl_env_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                C.c_int64, C.c_void_p]),
+                                C.c_void_p, C.c_int64, C.c_void_p]),
     'ttl_env_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -82,6 +82,8 @@ struct EnvParams {
     int *surv_pos;     // [n_max] position among survivors, -1 if stopped
     int *row_dest;     // [n_max] state row written for this active row
     int *block_counts; // [ceil(n_max/BLOCK)] survivors per block
+    int *proc_rank;    // [n_max] rank of a kept slot of the processing order
+    int *proc_counts;  // [ceil(n_max/BLOCK)] kept slots per block
     int *counts;       // {n_continue, n_stopped}
 };
 
@@ -240,8 +242,9 @@ __device__ __forceinline__ int stopping_bits(
 // Stable survivor ranks of one 256-thread block: 64-bit ballot per wavefront,
 // popcount of the lanes below, then the 4 wave totals through LDS.  Writes
 // rank[i] (survivors before row i inside the block) and the block's count.
-__device__ __forceinline__ void block_survivor_ranks(const EnvParams &P, int i,
-                                                     bool active, bool keep) {
+__device__ __forceinline__ void block_ranks(int *__restrict__ rank_out,
+                                            int *__restrict__ counts_out, int i,
+                                            bool active, bool keep) {
     const unsigned long long m = __ballot(keep);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -253,13 +256,18 @@ __device__ __forceinline__ void block_survivor_ranks(const EnvParams &P, int i,
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w)
         if (w < wave) before += wave_total[w];
-    if (active) P.rank[i] = before + below;
+    if (active) rank_out[i] = before + below;
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) tot += wave_total[w];
-        P.block_counts[blockIdx.x] = tot;
+        counts_out[blockIdx.x] = tot;
     }
+}
+
+__device__ __forceinline__ void block_survivor_ranks(const EnvParams &P, int i,
+                                                     bool active, bool keep) {
+    block_ranks(P.rank, P.block_counts, i, active, keep);
 }
 
 // ---------------------------------------------------------------------------
@@ -490,6 +498,45 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
 }
 
 // ---------------------------------------------------------------------------
+// Processing order of the state gather.  Row order (continue_idx order) is
+// fixed by the reference, but WHICH rows a workgroup gathers is free: proc[j]
+// lists the active rows sorted by the 8^3-voxel brick of their seed, so that a
+// workgroup -- and its neighbours in time on the same XCD -- fetch voxels that
+// are already in L2 instead of going to the Infinity Cache / HBM for each
+// streamline separately.  Each step proc is compacted (stable, in proc order)
+// and renumbered with the survivors' new row ids.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_proc_count(EnvParams P,
+                                                      const int *__restrict__ proc,
+                                                      int n_active) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = j < n_active;
+    const bool keep = active && P.stop[proc[active ? j : 0]] == 0;
+    block_ranks(P.proc_rank, P.proc_counts, j, active, keep);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
+                                                        const int *__restrict__ proc,
+                                                        int *__restrict__ proc_next,
+                                                        int n_active, int n_blocks) {
+    __shared__ int red[BLOCK / 64];
+    int before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) before += P.proc_counts[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = before;
+    __syncthreads();
+    before = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) before += red[w];
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_active) return;
+    const int row = proc[j];
+    const int pos = P.surv_pos[row];
+    if (pos >= 0) proc_next[before + P.proc_rank[j]] = pos;
+}
+
+// ---------------------------------------------------------------------------
 // k_state: LPS lanes per streamline, lane = one float4 column of the padded
 // voxel record, so a group reads each 16B-aligned voxel record as one
 // contiguous coef_pitch*4-byte segment.  7 points x 8 corners accumulate in
@@ -499,11 +546,13 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
 template <int LPS>
 __global__ __launch_bounds__(BLOCK) void k_state(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
-    int n_rows, int L, float *__restrict__ out, long long pitch) {
+    const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
+    long long pitch) {
     constexpr int ROWS = BLOCK / LPS;
-    const int row = blockIdx.x * ROWS + threadIdx.x / LPS;
+    const int slot = blockIdx.x * ROWS + threadIdx.x / LPS;
     const int sub = threadIdx.x % LPS;
-    if (row >= n_rows) return;
+    if (slot >= n_rows) return;
+    const int row = proc ? proc[slot] : slot;
     const int g = idx ? idx[row] : row;
     const int r = row_dest ? row_dest[row] : row;
     const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
@@ -632,13 +681,16 @@ __device__ __forceinline__ f4 sel4(bool c, f4 a, f4 b) {
 }
 __device__ __forceinline__ int clipi(int v, int n) { return min(max(v, 0), n - 1); }
 // store the float4 column c..c+3 of one point's C coefficients (the last
-// column of a padded record may be partial)
+// column of a padded record may be partial).  State rows are only 4-byte
+// aligned (W = 7C + 3K floats), so the full column goes out as ONE dword-
+// aligned 16-byte store (gfx950 global stores need dword alignment only)
+// instead of four strided dword stores: the row-per-lane-group epilogue is
+// store-issue bound otherwise.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef v4f v4f_dword_aligned __attribute__((aligned(4)));
 __device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
     if (c + 3 < C) {
-        o[0] = a.x;
-        o[1] = a.y;
-        o[2] = a.z;
-        o[3] = a.w;
+        *reinterpret_cast<v4f_dword_aligned *>(o) = v4f{a.x, a.y, a.z, a.w};
     } else {
         if (c + 0 < C) o[0] = a.x;
         if (c + 1 < C) o[1] = a.y;
@@ -649,11 +701,13 @@ __device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
 template <int LPS, int MINW, bool LOOP>
 __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
-    int n_rows, int L, float *__restrict__ out, long long pitch) {
+    const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
+    long long pitch) {
     constexpr int ROWS = BLOCK / LPS;
-    const int row = blockIdx.x * ROWS + threadIdx.x / LPS;
+    const int slot = blockIdx.x * ROWS + threadIdx.x / LPS;
     const int sub = threadIdx.x % LPS;
-    if (row >= n_rows) return;
+    if (slot >= n_rows) return;
+    const int row = proc ? proc[slot] : slot;
     const int g = idx ? idx[row] : row;
     const int r = row_dest ? row_dest[row] : row;
     const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
@@ -921,6 +975,9 @@ struct ttl_env {
     int last_order;
     int last_n;      // n_active of the pending step
     uint8_t *last_done;  // done_out of the pending step (k_restop updates it)
+    int *proc[2];        // processing order of the state gather, double buffered
+    int proc_cur;        // which proc buffer is current
+    int use_proc;        // a processing order was installed for this episode
     // optional per-kernel timing with HIP events on the caller's stream
     int state_kernel; // 0: k_state (all 56 corner fetches), else k_state_dd
     hipStream_t side;      // carries the early device->host copy of the counts
@@ -953,8 +1010,8 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     const size_t nb = (n + BLOCK - 1) / BLOCK + 1;
     size_t b = 0;
     b += align_up(n, 256);                    // stop
-    b += 3 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest
-    b += align_up(nb * sizeof(int), 256);     // block_counts
+    b += 6 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest, proc_rank, proc x2
+    b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
     return b;
 }
@@ -1049,6 +1106,10 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.surv_pos = (int *)w;        w += align_up(n * sizeof(int), 256);
     P.row_dest = (int *)w;        w += align_up(n * sizeof(int), 256);
     P.block_counts = (int *)w;    w += align_up(nb * sizeof(int), 256);
+    P.proc_rank = (int *)w;       w += align_up(n * sizeof(int), 256);
+    P.proc_counts = (int *)w;     w += align_up(nb * sizeof(int), 256);
+    e->proc[0] = (int *)w;        w += align_up(n * sizeof(int), 256);
+    e->proc[1] = (int *)w;        w += align_up(n * sizeof(int), 256);
     P.counts = (int *)w;
     e->length = 0;
     e->n_active = 0;
@@ -1057,6 +1118,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->last_order = TTL_ORDER_ACTIVE;
     e->last_n = 0;
     e->last_done = nullptr;
+    e->proc_cur = 0;
+    e->use_proc = 0;
     e->state_kernel = 4;
     if (const char *v = getenv("TTL_STATE_KERNEL")) e->state_kernel = atoi(v);
     e->side = nullptr;
@@ -1145,8 +1208,8 @@ int ttl_scripted_actions(const float *state, int64_t state_pitch, int32_t dir_of
 }
 
 static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
-                        int n_rows, int L, float *out, int64_t pitch,
-                        hipStream_t s) {
+                        const int *proc, int n_rows, int L, float *out,
+                        int64_t pitch, hipStream_t s) {
     const int C4 = env->P.coef_pitch >> 2;
     // the register-deduplicated kernel needs the shifted points to stay
     // within one cell of the centre: 0 < radius < 1 voxel
@@ -1159,10 +1222,11 @@ static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
         const dim3 grid((n_rows + (BLOCK / LPS) - 1) / (BLOCK / LPS));        \
         if (!dedupe)                                                          \
             hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, env->P, \
-                               idx, row_dest, n_rows, L, out, (long long)pitch); \
+                               idx, row_dest, proc, n_rows, L, out,           \
+                               (long long)pitch);                             \
         else                                                                  \
             hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32)>), grid, dim3(BLOCK), 0, s, \
-                               env->P, idx, row_dest, n_rows, L, out,         \
+                               env->P, idx, row_dest, proc, n_rows, L, out,   \
                                (long long)pitch);                             \
     } while (0)
     if (C4 <= 4) TTL_LAUNCH_STATE(4);
@@ -1174,7 +1238,8 @@ static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
     return TTL_OK;
 }
 
-int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n, float *state_out,
+int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
+                  const int32_t *processing_order, float *state_out,
                   int64_t state_pitch, void *hip_stream) {
     if (!env || !seeds || !state_out)
         return fail(TTL_ERR_INVALID, "ttl_env_reset: null argument");
@@ -1195,7 +1260,13 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n, float *state_out,
     env->length = 1;
     env->n_active = n;
     env->stepped = 0;
-    return launch_state(env, nullptr, nullptr, n, 1, state_out, state_pitch, s);
+    env->proc_cur = 0;
+    env->use_proc = processing_order != nullptr;
+    if (env->use_proc)
+        HIP_TRY(hipMemcpyAsync(env->proc[0], processing_order, (size_t)n * sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, s));
+    return launch_state(env, nullptr, nullptr, env->use_proc ? env->proc[0] : nullptr,
+                        n, 1, state_out, state_pitch, s);
 }
 
 int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
@@ -1281,8 +1352,19 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
     }
     env->stepped = 1;
     env->last_order = order;
+    const int *proc = nullptr;
+    if (env->use_proc) {
+        // next step's processing order: this one, compacted in its own order
+        // and renumbered with the survivors' new row ids
+        proc = env->proc[env->proc_cur];
+        hipLaunchKernelGGL(k_proc_count, dim3(nb), dim3(BLOCK), 0, s, env->P, proc,
+                           n_active);
+        hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, proc,
+                           env->proc[env->proc_cur ^ 1], n_active, nb);
+        HIP_TRY(hipGetLastError());
+    }
     prof_mark(env, 2, 0, s);
-    const int rc = launch_state(env, idx, env->P.row_dest, n_active, n_pts,
+    const int rc = launch_state(env, idx, env->P.row_dest, proc, n_active, n_pts,
                                 state_out, state_pitch, s);
     prof_mark(env, 2, 1, s);
     return rc;
@@ -1331,6 +1413,7 @@ int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
         }
     }
     env->cur ^= 1;
+    if (env->use_proc) env->proc_cur ^= 1;
     env->stepped = 0;
     // the caller learns the exact survivor count from host_counts; until then
     // the bound is the previous count
