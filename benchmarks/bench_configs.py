@@ -7,6 +7,10 @@ steps after 3 warm-up steps):
   c4-shard 145^3 (> Infinity Cache), 131072, K = 100, noisy env (float64
            directions): one GPU's shard of config 4
   c1       32^3, 4096, K = 100, noisy env (config 1's shape)
+  c2-host  config 2 through the reference's own calling contract: the action
+           batch crosses PCIe as a host numpy array, `step()` returns host
+           reward / dones, `harvest()` copies the survivors' rows
+           (the PCIe-inclusive rate)
 """
 import json
 import os
@@ -24,10 +28,13 @@ CONFIGS = {
     'c3-env': dict(D=96, N=65536, K=4, noisy=False, reward=True, max_length=200.0),
     'c4-shard': dict(D=145, N=131072, K=100, noisy=True, reward=False, max_length=300.0),
     'c1': dict(D=32, N=4096, K=100, noisy=True, reward=False, max_length=300.0),
+    'c2-host': dict(D=96, N=262144, K=4, noisy=False, reward=False,
+                    max_length=200.0, host_contract=True),
 }
 
 
-def run(name, D, N, K, noisy, reward, max_length, steps=12, warmup=3):
+def run(name, D, N, K, noisy, reward, max_length, steps=12, warmup=3,
+        host_contract=False):
     from tracktolearn_amd.environments import (NoisyTrackingEnvironment,
                                                TrackingEnvironment)
     from tracktolearn_amd.utils.synthetic import (synthetic_seeds,
@@ -53,7 +60,11 @@ def run(name, D, N, K, noisy, reward, max_length, steps=12, warmup=3):
                 break
             total += env._n_active
             a = env.scripted_actions(state, step, 1, 0.05)
-            env.step_device(a)
+            if host_contract:
+                # rl.py:93-94: action.to('cpu').numpy() -> env.step(numpy)
+                env.step(a.to(device='cpu', copy=True).numpy())
+            else:
+                env.step_device(a)
             state, _ = env.harvest()
         torch.cuda.synchronize()
         return total, time.perf_counter() - t0
@@ -67,6 +78,7 @@ def run(name, D, N, K, noisy, reward, max_length, steps=12, warmup=3):
     print(json.dumps({
         'config': name, 'volume': [D, D, D, 45], 'n_actor': N, 'n_dirs': K,
         'mode': 'f64dir' if noisy else 'f32', 'reward': reward,
+        'loop': 'step(numpy)+harvest (host contract)' if host_contract else 'step_device+harvest',
         'streamline_steps_per_s': total / dt, 'ms_per_step': dt / steps * 1e3,
         'k_state_ms': ms / max(n, 1),
         'k_state_algorithmic_GBs': kern_b * (total / max(n, 1)) / (ms / max(n, 1) * 1e-3) / 1e9,

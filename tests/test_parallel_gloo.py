@@ -78,3 +78,82 @@ def test_ragged_all_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, 'ok'), (1, 'ok')], results
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from tracktolearn_amd.algorithms.sac_auto import SACAuto
+        W, B = 27, 32
+        torch.manual_seed(100 + rank)            # different initial weights
+        alg = SACAuto(W, 3, '32-32', n_actors=8, batch_size=B, replay_size=100,
+                      rng=None, device=torch.device('cpu'))
+        alg.enable_data_parallel()
+        g = torch.Generator().manual_seed(7)
+        full = [torch.randn(2 * B, W, generator=g),
+                torch.tanh(torch.randn(2 * B, 3, generator=g)),
+                torch.randn(2 * B, W, generator=g), torch.rand(2 * B, generator=g),
+                (torch.rand(2 * B, generator=g) > 0.2).float()]
+        eps = [torch.randn(2 * B, 3, generator=g) for _ in range(2)]
+        calls = {'i': 0}
+
+        def noise(like):
+            calls['i'] += 1
+            return eps[calls['i'] % 2][rank * B:(rank + 1) * B]
+        alg.noise_fn = noise
+        mine = [t[rank * B:(rank + 1) * B] for t in full]     # this rank's half
+        for _ in range(3):
+            alg.update(mine)
+        flat = torch.cat([p.detach().reshape(-1) for p in
+                          list(alg.agent.actor.parameters()) +
+                          list(alg.agent.critic.parameters()) +
+                          list(alg.target.critic.parameters()) + [alg.log_alpha]])
+        q.put((rank, flat.numpy()))
+    except Exception as exc:          # pragma: no cover
+        q.put((rank, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_learner_world2_gloo():
+    """Two learner replicas on half batches each == one learner on the whole
+    batch: identical replicas, and equal (to rounding) to the single-process
+    update started from rank 0's weights."""
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(v, np.ndarray) for v in results.values()), results
+    assert np.array_equal(results[0], results[1])          # replicas identical
+    # single process, whole batch, rank 0's initial weights
+    W, B = 27, 32
+    torch.manual_seed(100)
+    alg = SACAuto(W, 3, '32-32', n_actors=8, batch_size=2 * B, replay_size=100,
+                  rng=None, device=torch.device('cpu'))
+    g = torch.Generator().manual_seed(7)
+    full = [torch.randn(2 * B, W, generator=g),
+            torch.tanh(torch.randn(2 * B, 3, generator=g)),
+            torch.randn(2 * B, W, generator=g), torch.rand(2 * B, generator=g),
+            (torch.rand(2 * B, generator=g) > 0.2).float()]
+    eps = [torch.randn(2 * B, 3, generator=g) for _ in range(2)]
+    calls = {'i': 0}
+
+    def noise(like):
+        calls['i'] += 1
+        return eps[calls['i'] % 2]
+    alg.noise_fn = noise
+    for _ in range(3):
+        alg.update(full)
+    flat = torch.cat([p.detach().reshape(-1) for p in
+                      list(alg.agent.actor.parameters()) +
+                      list(alg.agent.critic.parameters()) +
+                      list(alg.target.critic.parameters()) + [alg.log_alpha]]).numpy()
+    assert np.abs(flat - results[0]).max() < 5e-6

@@ -21,6 +21,35 @@ class SAC(DDPG):
         self.noise_fn = None
         self._graph = None
         self._graph_batch = None
+        #: data-parallel learner: every rank samples its own replay ring and
+        #: the gradients are averaged over the process group before each
+        #: optimizer step (see ``enable_data_parallel``)
+        self._dp_group = None
+        self._dp = False
+
+    def enable_data_parallel(self, group=None):
+        """One learner replica per GPU (the reference has a single learner;
+        SURVEY 8e): weights are broadcast from rank 0 once, then every
+        update averages the gradients with one flattened all-reduce per
+        network, so the replicas stay bit-identical while each consumes the
+        transitions of its own streamline shard."""
+        import torch.distributed as dist
+        from tracktolearn_amd.parallel import broadcast_parameters
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('enable_data_parallel needs torch.distributed')
+        if self._graph is not None:
+            raise RuntimeError('the graphed update is single-GPU only')
+        self._dp, self._dp_group = True, group
+        mods = [self.agent.actor, self.agent.critic, self.target.actor,
+                self.target.critic]
+        broadcast_parameters(mods, 0, group)
+        if hasattr(self, 'log_alpha'):
+            dist.broadcast(self.log_alpha.data, src=0, group=group)
+
+    def _sync_grads(self, params):
+        if self._dp:
+            from tracktolearn_amd.parallel import all_reduce_gradients
+            all_reduce_gradients(list(params), self._dp_group)
 
     # ------------------------------------------------------------------ #
     # HIP-graph replay of the update.  One update is ~150 small kernels
@@ -106,11 +135,13 @@ class SAC(DDPG):
     def _step_actor_critic(self, actor_loss, critic_loss):
         self.actor_optimizer.zero_grad()
         actor_loss.backward()
+        self._sync_grads(self.agent.actor.parameters())
         self.actor_optimizer.step()
         # the actor backward also left gradients on the critic; they are
         # discarded here, as in the reference
         self.critic_optimizer.zero_grad()
         critic_loss.backward()
+        self._sync_grads(self.agent.critic.parameters())
         self.critic_optimizer.step()
         self._polyak()
 

@@ -39,6 +39,7 @@ class SACAuto(SAC):
         actor_loss, critic_loss, _ = self._soft_q_losses(batch, alpha, pi, logp_pi)
         self.alpha_optimizer.zero_grad()
         alpha_loss.backward()
+        self._sync_grads([self.log_alpha])
         self.alpha_optimizer.step()
         self._step_actor_critic(actor_loss, critic_loss)
         return {}
