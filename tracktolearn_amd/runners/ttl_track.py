@@ -55,7 +55,8 @@ class TrackToLearnTrack(object):
         self.sh_basis = track_dto['sh_basis']
         self.save_seeds = track_dto['save_seeds']
         self.compute_reward = False
-        self.device = get_device()
+        self.device = torch.device('cuda', torch.cuda.current_device()) \
+            if torch.cuda.is_available() else get_device()
         self.fa_map = None
         self.agent = track_dto['agent']
         self.hyperparameters = track_dto['hyperparameters']
@@ -250,8 +251,15 @@ def main(argv=None):
     import torch.distributed as dist
     args = parse_args(argv)
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl')
+        # one process per GPU over RCCL.  Rehearsal on a single-GPU box:
+        # TTL_ONE_DEVICE=1 keeps every rank on cuda:0 and TTL_DIST_BACKEND=gloo
+        # replaces RCCL, which refuses two ranks on one device.
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        if os.environ.get('TTL_ONE_DEVICE') == '1':
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(os.environ.get('TTL_DIST_BACKEND', 'nccl'))
     experiment = TrackToLearnTrack(vars(args))
     experiment.run()
 
