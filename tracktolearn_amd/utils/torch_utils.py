@@ -1,17 +1,17 @@
-"""Device helpers (TrackToLearn/utils/torch_utils.py:3-15).  On this stack
-"cuda" is the MI355X through PyTorch-ROCm."""
+"""Device selection.  On this stack the torch "cuda" device IS the MI355X
+(PyTorch-ROCm); there is no MPS / CPU training path
+(cf. TrackToLearn/utils/torch_utils.py)."""
 import torch
 
 
 def get_device():
-    if torch.cuda.is_available():
-        return torch.device('cuda')
-    return torch.device('cpu')
-
-
-def assert_accelerator():
-    assert torch.cuda.is_available(), 'an MI355X (torch "cuda" device) is required'
+    return torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
 
 def get_device_str():
-    return str(get_device())
+    return get_device().type
+
+
+def assert_accelerator():
+    if not torch.cuda.is_available():
+        raise AssertionError('an MI355X (torch "cuda" device) is required')
