@@ -263,3 +263,91 @@ def test_edge_cases():
         assert np.array_equal(env.flags, ref.flags)
         assert np.array_equal(env.continue_idx, ref.continue_idx)
     assert env.get_state_size() == 7 * 45 + 12
+
+
+def _anisotropic_subject(shape, C=45, seed=77):
+    """Non-cubic volumes: catches any x/y/z stride mix-up."""
+    from tracktolearn_amd.datasets.utils import MRIDataVolume as Vol
+    rng = np.random.RandomState(seed)
+    X, Y, Z = shape
+    sh = (0.1 * rng.standard_normal((X, Y, Z, C))).astype(np.float32)
+    sh[..., 0] = 1.0
+    g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z),
+                             indexing='ij')).astype(np.float64)
+    centre = np.array([(X - 1) / 2, (Y - 1) / 2, (Z - 1) / 2])[:, None, None, None]
+    radii = np.array([0.42 * X, 0.42 * Y, 0.42 * Z])[:, None, None, None]
+    mask = ((((g - centre) / radii) ** 2).sum(0) < 1.0).astype(np.uint8)
+    pk = rng.standard_normal((X, Y, Z, 15)).astype(np.float32)
+    aff = np.eye(4, dtype=np.float32)
+    return (Vol(sh, aff), Vol(mask, aff), Vol(mask, aff), Vol(pk, aff), None), sh, mask, pk
+
+
+@pytest.mark.parametrize('theta,thr', [(30.0, 0.1), (20.0, 0.5), (60.0, 0.3), (90.0, 0.1)])
+def test_non_cubic_volume_other_angles_and_thresholds(theta, thr, monkeypatch):
+    """18 x 26 x 34 volume (all strides differ), several curvature angles and
+    mask thresholds, brick-sorted processing order on: HIP env vs oracle."""
+    from oracle import env_oracle as orc
+    from tracktolearn_amd.environments import TrackingEnvironment
+    monkeypatch.setattr(TrackingEnvironment, 'SPATIAL_ORDER_MIN', 1)
+    shape = (18, 26, 34)
+    subject, sh, mask, pk = _anisotropic_subject(shape)
+    N = 3000
+    rng = np.random.RandomState(5)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    dto = _dto(n_dirs=4, theta=theta, max_length=25.0, reward=True, thr=thr)
+    env = TrackingEnvironment(subject, 'testing', dto)
+    env.seeds = seeds
+    ref = orc.OracleTrackingEnv(
+        sh, mask, seeds, n_dirs=4, theta=theta, step_size=env.step_size,
+        max_nb_steps=env.max_nb_steps, mask_threshold=thr, peaks=pk,
+        compute_reward=True, alignment_weighting=1.0)
+    s_hip, s_ref = env.reset(0, N), ref.reset(0, N)
+    assert _close(s_hip.cpu().numpy(), s_ref)
+    step = 0
+    while len(ref.continue_idx):
+        a = _scripted(rng, s_ref, 7 * 45, step, 0.35)
+        ns_hip, r_hip, d_hip, _ = env.step(a.copy())
+        ns_ref, r_ref, d_ref, _ = ref.step(a.copy())
+        assert np.array_equal(d_hip, d_ref)
+        assert _close(ns_hip.cpu().numpy(), ns_ref)
+        assert _close(r_hip, r_ref)
+        s_hip, _ = env.harvest()
+        s_ref, _ = ref.harvest()
+        step += 1
+    assert np.array_equal(env.flags, ref.flags)
+    assert np.array_equal(env.streamlines, ref.streamlines)
+    assert (ref.flags & 4).any() and (ref.flags & 1).any()
+
+
+def test_noisy_env_with_host_rng_noise():
+    """NoisyTrackingEnvironment with sigma > 0: the noise is drawn from
+    env_dto['rng'] on the host exactly as the reference does
+    (noisy_tracking_env.py:73-77), so equal RandomStates give bit-identical
+    tracks."""
+    from oracle import env_oracle as orc
+    D, N = 20, 2048
+    sh, mask, pk = synthetic_subject(D)
+    rng = np.random.RandomState(8)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    env = _hip_env(D, noisy=True, affine_dtype=np.float64, seeds=seeds, n_dirs=4,
+                   max_length=25.0, reward=False, noise=0.08)
+    env.rng = np.random.RandomState(4242)
+    ref = orc.OracleNoisyTrackingEnv(
+        sh, mask, seeds, noise=0.08, rng=np.random.RandomState(4242), n_dirs=4,
+        theta=30.0, step_size=env.step_size, max_nb_steps=env.max_nb_steps,
+        mask_threshold=0.1, peaks=pk, compute_reward=False)
+    s_hip, s_ref = env.reset(0, N), ref.reset(0, N)
+    step = 0
+    while len(ref.continue_idx):
+        a = _scripted(rng, s_ref, 7 * 45, step, 0.1)
+        _, _, d_hip, _ = env.step(a.copy())
+        _, _, d_ref, _ = ref.step(a.copy())
+        assert np.array_equal(d_hip, d_ref)
+        s_hip, _ = env.harvest()
+        s_ref, _ = ref.harvest()
+        step += 1
+    assert step > 3
+    assert np.array_equal(env.streamlines, ref.streamlines)
+    assert np.array_equal(env.flags, ref.flags)
