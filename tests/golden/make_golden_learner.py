@@ -127,6 +127,93 @@ def td3(ref_mods):
     _save('learner_td3', out)
 
 
+def sac_fixed_alpha(ref_mods):
+    from TrackToLearn.algorithms.sac import SAC
+    import torch.distributions.normal as tdn
+    W, A, B = 27, 3, 64
+    torch.manual_seed(2)
+    alg = SAC(W, A, '32-32', lr=3e-4, gamma=0.99, alpha=0.2, n_actors=8,
+              batch_size=B, replay_size=1000, rng=np.random.RandomState(0),
+              device=torch.device('cpu'))
+    out = {}
+    _flat('init/actor', alg.agent.actor.state_dict(), out)
+    _flat('init/critic', alg.agent.critic.state_dict(), out)
+    rng = np.random.RandomState(8)
+    batch = [rng.standard_normal((B, W)).astype(np.float32),
+             np.tanh(rng.standard_normal((B, A))).astype(np.float32),
+             rng.standard_normal((B, W)).astype(np.float32),
+             rng.uniform(-1, 1, B).astype(np.float32),
+             (rng.uniform(size=B) > 0.2).astype(np.float32)]
+    for n, b in zip(['state', 'action', 'next_state', 'reward', 'not_done'], batch):
+        out[f'batch/{n}'] = b
+    n_updates = 3
+    eps = rng.standard_normal((n_updates, 2, B, A)).astype(np.float32)
+    out['eps'] = eps
+    calls = {'i': 0}
+    orig = tdn._standard_normal
+
+    def replay(shape, dtype, device):
+        e = torch.from_numpy(eps.reshape(-1, B, A)[calls['i']])
+        calls['i'] += 1
+        return e
+    tdn._standard_normal = replay
+    try:
+        tb = [torch.from_numpy(b) for b in batch]
+        for u in range(n_updates):
+            losses = alg.update(tb)
+            out[f'u{u}/critic_loss'] = np.float64(losses['critic_loss'])
+            out[f'u{u}/actor_loss'] = np.float64(losses['actor_loss'])
+            _flat(f'u{u}/actor', alg.agent.actor.state_dict(), out)
+            _flat(f'u{u}/critic', alg.agent.critic.state_dict(), out)
+            _flat(f'u{u}/target_critic', alg.target.critic.state_dict(), out)
+    finally:
+        tdn._standard_normal = orig
+    out['n_updates'] = n_updates
+    _save('learner_sac', out)
+
+
+def ddpg(ref_mods):
+    from TrackToLearn.algorithms.ddpg import DDPG
+    W, A, B = 27, 3, 64
+    torch.manual_seed(4)
+    alg = DDPG(W, A, '32-32', action_std=0.35, lr=3e-4, gamma=0.99, n_actors=8,
+               batch_size=B, replay_size=1000, rng=np.random.RandomState(0),
+               device=torch.device('cpu'))
+    out = {}
+    _flat('init/actor', alg.agent.actor.state_dict(), out)
+    _flat('init/critic', alg.agent.critic.state_dict(), out)
+    rng = np.random.RandomState(9)
+    batch = [rng.standard_normal((B, W)).astype(np.float32),
+             np.tanh(rng.standard_normal((B, A))).astype(np.float32),
+             rng.standard_normal((B, W)).astype(np.float32),
+             rng.uniform(-1, 1, B).astype(np.float32),
+             (rng.uniform(size=B) > 0.2).astype(np.float32)]
+    for n, b in zip(['state', 'action', 'next_state', 'reward', 'not_done'], batch):
+        out[f'batch/{n}'] = b
+    n_updates = 3
+    eps = rng.standard_normal((n_updates, B, A)).astype(np.float32)
+    out['eps'] = eps
+    calls = {'i': 0}
+    orig = torch.randn_like
+
+    def replay(t, **kw):
+        e = torch.from_numpy(eps[calls['i']])
+        calls['i'] += 1
+        return e
+    torch.randn_like = replay
+    try:
+        tb = [torch.from_numpy(b) for b in batch]
+        for u in range(n_updates):
+            alg.update(tb)
+            _flat(f'u{u}/actor', alg.agent.actor.state_dict(), out)
+            _flat(f'u{u}/critic', alg.agent.critic.state_dict(), out)
+            _flat(f'u{u}/target_actor', alg.target.actor.state_dict(), out)
+    finally:
+        torch.randn_like = orig
+    out['n_updates'] = n_updates
+    _save('learner_ddpg', out)
+
+
 def replay_buffer(ref_mods):
     from TrackToLearn.algorithms.shared.replay import OffPolicyReplayBuffer
     buf = OffPolicyReplayBuffer(5, 3, max_size=10)
@@ -157,4 +244,6 @@ if __name__ == '__main__':
     mods = import_reference()
     sac_auto(mods)
     td3(mods)
+    sac_fixed_alpha(mods)
+    ddpg(mods)
     replay_buffer(mods)

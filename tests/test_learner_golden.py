@@ -121,3 +121,40 @@ def test_checkpoint_round_trip(tmp_path):
     b.load(str(tmp_path), 'last_model_state')
     x = torch.randn(5, 27)
     assert torch.equal(a.select_action(x, 0.0), b.select_action(x, 0.0))
+
+
+def test_sac_fixed_alpha_update_matches_reference():
+    from tracktolearn_amd.algorithms.sac import SAC
+    z = load_trace('learner_sac')
+    alg = SAC(27, 3, '32-32', lr=3e-4, gamma=0.99, alpha=0.2, n_actors=8,
+              batch_size=64, replay_size=1000, rng=None, device=CPU)
+    alg.agent.load_state_dict((_load_sd(z, 'init/actor'), _load_sd(z, 'init/critic')))
+    alg.target.load_state_dict((_load_sd(z, 'init/actor'), _load_sd(z, 'init/critic')))
+    assert alg.start_timesteps == 1000
+    eps = iter(torch.from_numpy(z['eps']).reshape(-1, 64, 3))
+    alg.noise_fn = lambda like: next(eps)
+    batch = _batch(z)
+    for u in range(int(z['n_updates'])):
+        losses = alg.update(batch)
+        assert abs(float(losses['critic_loss']) - float(z[f'u{u}/critic_loss'])) < 1e-5
+        assert abs(float(losses['actor_loss']) - float(z[f'u{u}/actor_loss'])) < 1e-5
+        _check_sd(alg.agent.actor, z, f'u{u}/actor', 2e-6)
+        _check_sd(alg.agent.critic, z, f'u{u}/critic', 2e-6)
+        _check_sd(alg.target.critic, z, f'u{u}/target_critic', 2e-6)
+
+
+def test_ddpg_update_matches_reference(monkeypatch):
+    from tracktolearn_amd.algorithms.ddpg import DDPG
+    z = load_trace('learner_ddpg')
+    alg = DDPG(27, 3, '32-32', action_std=0.35, lr=3e-4, gamma=0.99, n_actors=8,
+               batch_size=64, replay_size=1000, rng=None, device=CPU)
+    alg.agent.load_state_dict((_load_sd(z, 'init/actor'), _load_sd(z, 'init/critic')))
+    alg.target.load_state_dict((_load_sd(z, 'init/actor'), _load_sd(z, 'init/critic')))
+    eps = iter(torch.from_numpy(z['eps']))
+    monkeypatch.setattr(torch, 'randn_like', lambda t, **kw: next(eps))
+    batch = _batch(z)
+    for u in range(int(z['n_updates'])):
+        alg.update(batch)
+        _check_sd(alg.agent.actor, z, f'u{u}/actor', 2e-6)
+        _check_sd(alg.agent.critic, z, f'u{u}/critic', 2e-6)
+        _check_sd(alg.target.actor, z, f'u{u}/target_actor', 2e-6)
