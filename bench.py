@@ -206,6 +206,21 @@ def main():
     torch.cuda.synchronize()
     prof_all = env.profile_end()
 
+    # ---- whole episode to exhaustion; outside the K-step
+    # region of the contract, reported as `whole_episode` -------------------
+    state = env.reset(0, N_ACTOR)
+    torch.cuda.synchronize()
+    t_ep = time.perf_counter()
+    ep_units, ep_steps = 0, 0
+    while env._n_active:
+        ep_units += env._n_active
+        actions = env.scripted_actions(state, ep_steps, seed, WOBBLE)
+        env.step_device(actions)
+        state, _ = env.harvest()
+        ep_steps += 1
+    torch.cuda.synchronize()
+    t_ep = time.perf_counter() - t_ep
+
     # ---- collate finished tracts (the path's only exchange step) ----------
     collate_ms = None
     if world > 1:
@@ -283,6 +298,9 @@ def main():
                     'prefix': pre_ms / max(adv_n, 1)},
             },
         }
+        line['whole_episode'] = {
+            'streamline_steps_per_s_rank0': ep_units / t_ep, 'steps': ep_steps,
+            'streamline_steps': ep_units, 'ms': t_ep * 1e3}
         if collate_ms is not None:
             line['collate_ms'] = collate_ms
         if not args.no_cpu_baseline and world == 1:
