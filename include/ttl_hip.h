@@ -183,7 +183,9 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
                      void *hip_stream);
 
 /* Blocks the calling host thread until the host_counts of the last
- * ttl_env_step() have landed (not until the step has finished). */
+ * ttl_env_step() have landed (not until the step has finished).  Called after
+ * ttl_env_harvest() it also tells the handle the exact survivor count, and
+ * the next ttl_env_step() is then refused unless n_active equals it. */
 int ttl_env_wait_counts(ttl_env *env);
 
 /* TrackingEnvironment.harvest (tracking_env.py:223-245): lengths of the
@@ -232,6 +234,8 @@ int ttl_scripted_actions(const float *state, int64_t state_pitch,
 
 const char *ttl_last_error(void);
 uint32_t ttl_abi_version(void);
+/* sizeof(ttl_env_desc) as compiled: a binding checks its own struct against it */
+size_t ttl_env_desc_size(void);
 
 #ifdef __cplusplus
 }

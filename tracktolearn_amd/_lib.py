@@ -99,6 +99,7 @@ SYMBOLS = {
                                        C.c_void_p]),
     'ttl_last_error': (C.c_char_p, []),
     'ttl_abi_version': (C.c_uint32, []),
+    'ttl_env_desc_size': (C.c_size_t, []),
 }
 
 _lib = None
@@ -121,6 +122,10 @@ def load():
         fn.argtypes = args
     if lib.ttl_abi_version() != ABI_VERSION:
         raise TTLError('libttl_hip.so ABI version mismatch')
+    if lib.ttl_env_desc_size() != C.sizeof(EnvDesc):
+        raise TTLError('ttl_env_desc layout mismatch between libttl_hip.so '
+                       f'({lib.ttl_env_desc_size()} B) and the ctypes mirror '
+                       f'({C.sizeof(EnvDesc)} B)')
     _lib = lib
     return lib
 

@@ -996,6 +996,8 @@ struct ttl_env {
     hipEvent_t ev_prefix;  // main stream: k_prefix done (counts are final)
     hipEvent_t ev_counts;  // side stream: counts have landed in host memory
     int counts_pending;    // an early copy is in flight / unread
+    const int32_t *host_counts;  // where that copy lands (caller's pinned memory)
+    int n_exact;           // n_active is the exact survivor count (read back)
     int prof_on;
     int prof_mask;    // bit k: time kernel class k
     int prof_cap;     // event pairs available per kernel class
@@ -1015,6 +1017,7 @@ extern "C" {
 
 const char *ttl_last_error(void) { return g_err; }
 uint32_t ttl_abi_version(void) { return TTL_ABI_VERSION; }
+size_t ttl_env_desc_size(void) { return sizeof(ttl_env_desc); }
 
 size_t ttl_env_workspace_bytes(int32_t n_max) {
     if (n_max < 0) return 0;
@@ -1140,6 +1143,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->ev_prefix = nullptr;
     e->ev_counts = nullptr;
     e->counts_pending = 0;
+    e->host_counts = nullptr;
+    e->n_exact = 0;
     e->prof_mask = 7;
     e->prof_on = 0;
     e->prof_cap = 0;
@@ -1273,6 +1278,7 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
     env->cur = 0;
     env->length = 1;
     env->n_active = n;
+    env->n_exact = 1;
     env->stepped = 0;
     env->proc_cur = 0;
     env->use_proc = processing_order != nullptr;
@@ -1290,9 +1296,10 @@ int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
         return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
     if (env->length < 1) return fail(TTL_ERR_STATE, "ttl_env_step: reset first");
     if (env->stepped) return fail(TTL_ERR_STATE, "ttl_env_step: harvest the previous step first");
-    if (n_active < 1 || n_active > env->n_active)
-        return fail(TTL_ERR_INVALID, "ttl_env_step: n_active=%d outside [1, %d]",
-                    n_active, env->n_active);
+    if (n_active < 1 || n_active > env->n_active ||
+        (env->n_exact && n_active != env->n_active))
+        return fail(TTL_ERR_INVALID, "ttl_env_step: n_active=%d, but %s%d streamlines are active",
+                    n_active, env->n_exact ? "" : "at most ", env->n_active);
     const ttl_env_desc &d = env->d;
     if (env->length > d.max_nb_steps)
         return fail(TTL_ERR_STATE, "ttl_env_step: streamline history is full");
@@ -1363,6 +1370,7 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
                                hipMemcpyDeviceToHost, env->side));
         HIP_TRY(hipEventRecord(env->ev_counts, env->side));
         env->counts_pending = 1;
+        env->host_counts = host_counts;
     }
     env->stepped = 1;
     env->last_order = order;
@@ -1429,9 +1437,10 @@ int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
     env->cur ^= 1;
     if (env->use_proc) env->proc_cur ^= 1;
     env->stepped = 0;
-    // the caller learns the exact survivor count from host_counts; until then
-    // the bound is the previous count
+    // until ttl_env_wait_counts() has read the survivor count back, the
+    // previous count is only an upper bound
     env->n_active = n;
+    env->n_exact = 0;
     return TTL_OK;
 }
 
@@ -1441,6 +1450,12 @@ int ttl_env_wait_counts(ttl_env *env) {
         return fail(TTL_ERR_STATE, "ttl_env_wait_counts: the last step had no host_counts");
     HIP_TRY(hipEventSynchronize(env->ev_counts));
     env->counts_pending = 0;
+    // the handle now knows the exact number of survivors: the next step must
+    // be launched for exactly that many rows
+    if (env->host_counts && !env->stepped) {
+        env->n_active = env->host_counts[0];
+        env->n_exact = 1;
+    }
     return TTL_OK;
 }
 
