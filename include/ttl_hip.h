@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTL_ABI_VERSION 4
+#define TTL_ABI_VERSION 5
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -86,6 +86,10 @@ typedef struct ttl_env_desc {
     int32_t mask_dim[3];
     const double *mask_coef;
     double mask_threshold; /* env_dto['binary_stopping_threshold']           */
+    /* optional [X][Y][Z] u8 from ttl_mask_classes(mask_coef, mask_dim,
+     * mask_threshold): cells where the spline cannot cross the threshold are
+     * decided without evaluating it (same decisions, bit for bit); or NULL  */
+    const uint8_t *mask_classes;
 
     /* fODF peaks for the alignment reward: [X][Y][Z][15] f32, or NULL       */
     int32_t peaks_dim[3];
@@ -125,6 +129,12 @@ size_t ttl_env_workspace_bytes(int32_t n_max);
  * records [X][Y][Z][coef_pitch], zero padded.  Once per subject. */
 int ttl_pack_sh_volume(const float *src, float *dst, int64_t n_voxels,
                        int32_t n_coef, int32_t coef_pitch, void *hip_stream);
+
+/* Per-cell shortcut table for the mask test (see ttl_env_desc.mask_classes):
+ * 1 = all 64 spline taps of the cell are >= threshold, 2 = all are below,
+ * 0 = undecided.  Once per subject and threshold. */
+int ttl_mask_classes(const double *mask_coef, const int32_t *dim /*[3]*/,
+                     double threshold, uint8_t *classes_out, void *hip_stream);
 
 /* Validates the descriptor and creates a handle (no device work).
  * Replaces the per-subject setup of BaseEnv.load_subject, env.py:143-281. */

@@ -351,3 +351,41 @@ def test_noisy_env_with_host_rng_noise():
     assert step > 3
     assert np.array_equal(env.streamlines, ref.streamlines)
     assert np.array_equal(env.flags, ref.flags)
+
+
+def test_mask_class_shortcut_changes_no_decision(monkeypatch):
+    """The per-cell class table (ttl_mask_classes) only skips spline
+    evaluations whose outcome is certain: decisions with and without it agree
+    on random points, on points hugging every border and cell corner, and with
+    scipy; and it really does decide most cells."""
+    from scipy.ndimage import map_coordinates
+    z = load_trace('isolated_functions')
+    D = z['mask_in'].shape[0]
+    rng = np.random.RandomState(12)
+    pts = np.concatenate([
+        z['mask_pts'],
+        rng.uniform(-1.0, D + 1.0, (200000, 3)).astype(np.float32),
+        (rng.randint(0, D + 1, (20000, 3)) + 0.5 +
+         rng.choice([-1e-6, 0.0, 1e-6], (20000, 3))).astype(np.float32)])
+    results = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TTL_MASK_CLASSES', flag)
+        for thr in (0.1, 0.5, 0.9):
+            env = _hip_env(D, noisy=False, affine_dtype=np.float32,
+                           seeds=np.zeros((1, 3)), n_dirs=4, max_length=1000.0,
+                           reward=False, thr=thr)
+            stop, _ = env._compute_stopping_flags(pts[:, None, :])
+            results[(flag, thr)] = stop
+            if flag == '1':
+                cls = env._mask_cls.cpu().numpy()
+                # a 12^3 volume is mostly boundary shell; the 96^3 benchmark
+                # volume decides > 80 % of its cells this way
+                assert (cls == 0).any() and (cls != 0).any()
+                assert set(np.unique(cls)) <= {0, 1, 2}
+            else:
+                assert env._mask_cls is None
+    coef = z['mask_coef']
+    vals = map_coordinates(coef, pts.T - np.float32(0.5), prefilter=False)
+    for thr in (0.1, 0.5, 0.9):
+        assert np.array_equal(results[('1', thr)], results[('0', thr)])
+        assert np.array_equal(results[('1', thr)], vals < thr)

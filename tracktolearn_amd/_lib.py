@@ -18,7 +18,7 @@ import torch  # noqa: F401  (keep above the CDLL below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MODE_F32 = 0
 MODE_F64DIR = 1
 MODE_F32NORM = 2
@@ -43,6 +43,7 @@ class EnvDesc(C.Structure):
         ('mask_dim', C.c_int32 * 3),
         ('mask_coef', C.c_void_p),
         ('mask_threshold', C.c_double),
+        ('mask_classes', C.c_void_p),
         ('peaks_dim', C.c_int32 * 3),
         ('peaks', C.c_void_p),
         ('compute_reward', C.c_int32),
@@ -70,6 +71,8 @@ SYMBOLS = {
     'ttl_env_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'ttl_pack_sh_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_int32, C.c_void_p]),
+    'ttl_mask_classes': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_double,
+                                   C.c_void_p, C.c_void_p]),
     'ttl_env_create': (C.c_int, [C.POINTER(EnvDesc), C.POINTER(C.c_void_p)]),
     'ttl_env_destroy': (None, [C.c_void_p]),
     'ttl_env_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

@@ -60,6 +60,7 @@ struct EnvParams {
     float sh_shift;
     int mask_dim[3];
     const double *mask_coef;
+    const uint8_t *mask_cls;  // per-cell class (see k_mask_classes) or null
     double mask_thr;
     int peaks_dim[3];
     const float *peaks;
@@ -128,6 +129,16 @@ __device__ bool outside_mask(const EnvParams &P, float px, float py, float pz) {
                         (cz >= 0.0 && cz <= (double)(nz - 1));
     if (!inside) return 0.0 < P.mask_thr;
     const double fx = floor(cx), fy = floor(cy), fz = floor(cz);
+    if (P.mask_cls) {
+        // cubic B-spline weights are non-negative and sum to 1, so the value
+        // lies between the smallest and the largest of the 64 taps: cells
+        // whose taps are all on one side of the threshold (with a rounding
+        // margin, k_mask_classes) are decided by this one byte
+        const uint8_t cls =
+            P.mask_cls[((size_t)(int)fx * ny + (int)fy) * nz + (int)fz];
+        if (cls == 1) return false;
+        if (cls == 2) return true;
+    }
     double wx[4], wy[4], wz[4];
     cubic_weights(cx, fx, wx);
     cubic_weights(cy, fy, wy);
@@ -973,6 +984,42 @@ __global__ __launch_bounds__(BLOCK) void k_scripted_actions(
     actions[(size_t)i * 3 + 2] = a2;
 }
 
+// ---------------------------------------------------------------------------
+// k_mask_classes: for every cell (the integer part of a sample coordinate)
+// the min / max of the 64 mirror-folded coefficient taps a sample in that
+// cell would read.  1 = every sample there is >= thr (never stops), 2 = every
+// sample is < thr (always stops), 0 = evaluate the spline.  The margin covers
+// the rounding of the float64 evaluation (weights sum to 1 within a few ulp,
+// 64 products and additions: error << 1e-12 * max|c|).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_mask_classes(
+    const double *__restrict__ coef, int nx, int ny, int nz, double thr,
+    uint8_t *__restrict__ cls) {
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long total = (long long)nx * ny * nz;
+    if (t >= total) return;
+    const int fz = (int)(t % nz), fy = (int)((t / nz) % ny), fx = (int)(t / ((long long)nz * ny));
+    double lo = INFINITY, hi = -INFINITY;
+    for (int a = 0; a < 4; ++a) {
+        const int ia = mirror_fold(fx - 1 + a, nx);
+        for (int b = 0; b < 4; ++b) {
+            const int ib = mirror_fold(fy - 1 + b, ny);
+            const double *line = coef + ((size_t)ia * ny + ib) * nz;
+            for (int d = 0; d < 4; ++d) {
+                const double v = line[mirror_fold(fz - 1 + d, nz)];
+                lo = fmin(lo, v);
+                hi = fmax(hi, v);
+            }
+        }
+    }
+    const double margin = 1e-9 * (1.0 + fabs(thr) + fmax(fabs(lo), fabs(hi)));
+    uint8_t c = 0;
+    if (lo >= thr + margin) c = 1;
+    else if (hi < thr - margin) c = 2;
+    if (!(lo == lo) || !(hi == hi)) c = 0;   // NaN coefficients: evaluate
+    cls[t] = c;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -1049,6 +1096,18 @@ int ttl_pack_sh_volume(const float *src, float *dst, int64_t n_voxels,
     return TTL_OK;
 }
 
+int ttl_mask_classes(const double *mask_coef, const int32_t *dim, double threshold,
+                     uint8_t *classes_out, void *hip_stream) {
+    if (!mask_coef || !dim || !classes_out || dim[0] < 1 || dim[1] < 1 || dim[2] < 1)
+        return fail(TTL_ERR_INVALID, "ttl_mask_classes: bad arguments");
+    const long long total = (long long)dim[0] * dim[1] * dim[2];
+    hipLaunchKernelGGL(k_mask_classes, dim3((unsigned)((total + BLOCK - 1) / BLOCK)),
+                       dim3(BLOCK), 0, (hipStream_t)hip_stream, mask_coef, dim[0],
+                       dim[1], dim[2], threshold, classes_out);
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
+}
+
 int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     if (!desc || !out) return fail(TTL_ERR_INVALID, "ttl_env_create: null argument");
     const ttl_env_desc &d = *desc;
@@ -1098,6 +1157,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.sh = d.sh_packed;
     P.sh_shift = d.sh_coord_shift;
     P.mask_coef = d.mask_coef;
+    P.mask_cls = d.mask_classes;
     P.mask_thr = d.mask_threshold;
     P.peaks = d.peaks;
     P.compute_reward = d.compute_reward;

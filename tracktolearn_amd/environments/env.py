@@ -12,6 +12,7 @@ include/ttl_hip.h).  There is no CPU path: a non-CUDA device or a missing
 library raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -179,6 +180,16 @@ class BaseEnv(object):
         coef = mask_spline_coefficients(mask_data)
         self._mask_coef = torch.from_numpy(coef).to(self.device)
         self._mask_dim = tuple(int(d) for d in coef.shape)
+        # per-cell shortcut of the mask test (decisions unchanged)
+        self._mask_cls = None
+        if os.environ.get('TTL_MASK_CLASSES', '1') != '0':
+            self._mask_cls = torch.empty(self._mask_dim, dtype=torch.uint8,
+                                         device=self.device)
+            dims = (C.c_int32 * 3)(*self._mask_dim)
+            _lib.check(self._lib.ttl_mask_classes(
+                self._mask_coef.data_ptr(), dims,
+                float(self.binary_stopping_threshold),
+                self._mask_cls.data_ptr(), stream), 'ttl_mask_classes')
 
         self._peaks_dev = None
         self._peaks_dim = (0, 0, 0)
@@ -272,6 +283,8 @@ class BaseEnv(object):
         d.mask_dim[:] = self._mask_dim
         d.mask_coef = self._mask_coef.data_ptr()
         d.mask_threshold = float(self.binary_stopping_threshold)
+        d.mask_classes = self._mask_cls.data_ptr() \
+            if self._mask_cls is not None else None
         d.peaks_dim[:] = self._peaks_dim
         d.peaks = self._peaks_dev.data_ptr() if self._peaks_dev is not None else None
         d.compute_reward = 1 if self.compute_reward else 0
