@@ -146,6 +146,9 @@ def main():
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--whole-episode', action='store_true',
+                    help='also run one episode to exhaustion after the timed '
+                         'region (SURVEY 8d (ii)) and report it as whole_episode')
     args = ap.parse_args()
 
     import torch
@@ -206,20 +209,24 @@ def main():
     torch.cuda.synchronize()
     prof_all = env.profile_end()
 
-    # ---- whole episode to exhaustion; outside the K-step
-    # region of the contract, reported as `whole_episode` -------------------
-    state = env.reset(0, N_ACTOR)
-    torch.cuda.synchronize()
-    t_ep = time.perf_counter()
-    ep_units, ep_steps = 0, 0
-    while env._n_active:
-        ep_units += env._n_active
-        actions = env.scripted_actions(state, ep_steps, seed, WOBBLE)
-        env.step_device(actions)
-        state, _ = env.harvest()
-        ep_steps += 1
-    torch.cuda.synchronize()
-    t_ep = time.perf_counter() - t_ep
+    # ---- optional: whole episode to exhaustion, outside the
+    # K-step region of the contract ----------------------------------------
+    ep = None
+    if args.whole_episode:
+        state = env.reset(0, N_ACTOR)
+        torch.cuda.synchronize()
+        t_ep = time.perf_counter()
+        ep_units, ep_steps = 0, 0
+        while env._n_active:
+            ep_units += env._n_active
+            actions = env.scripted_actions(state, ep_steps, seed, WOBBLE)
+            env.step_device(actions)
+            state, _ = env.harvest()
+            ep_steps += 1
+        torch.cuda.synchronize()
+        t_ep = time.perf_counter() - t_ep
+        ep = {'streamline_steps_per_s_rank0': ep_units / t_ep, 'steps': ep_steps,
+              'streamline_steps': ep_units, 'ms': t_ep * 1e3}
 
     # ---- collate finished tracts (the path's only exchange step) ----------
     collate_ms = None
@@ -298,9 +305,8 @@ def main():
                     'prefix': pre_ms / max(adv_n, 1)},
             },
         }
-        line['whole_episode'] = {
-            'streamline_steps_per_s_rank0': ep_units / t_ep, 'steps': ep_steps,
-            'streamline_steps': ep_units, 'ms': t_ep * 1e3}
+        if ep is not None:
+            line['whole_episode'] = ep
         if collate_ms is not None:
             line['collate_ms'] = collate_ms
         if not args.no_cpu_baseline and world == 1:
