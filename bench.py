@@ -229,14 +229,17 @@ def main():
               'streamline_steps': ep_units, 'ms': t_ep * 1e3}
 
     # ---- collate finished tracts (the path's only exchange step) ----------
-    collate_ms = None
+    collate_ms, collate_error = None, None
     if world > 1:
-        from tracktolearn_amd.parallel import all_gather_tract_index
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        all_gather_tract_index(env)
-        torch.cuda.synchronize()
-        collate_ms = (time.perf_counter() - t1) * 1e3
+        try:
+            from tracktolearn_amd.parallel import all_gather_tract_index
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            all_gather_tract_index(env)
+            torch.cuda.synchronize()
+            collate_ms = (time.perf_counter() - t1) * 1e3
+        except Exception as exc:      # never lose the bench line to the collate
+            collate_error = repr(exc)
 
     red_dev = device if backend == 'nccl' else 'cpu'
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -309,6 +312,8 @@ def main():
             line['whole_episode'] = ep
         if collate_ms is not None:
             line['collate_ms'] = collate_ms
+        if collate_error is not None:
+            line['collate_error'] = collate_error
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(subject[1].data, subject[0].data)
         elif not args.no_cpu_baseline:
