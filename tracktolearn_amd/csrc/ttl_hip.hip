@@ -560,10 +560,13 @@ __global__ __launch_bounds__(BLOCK) void k_state(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
     const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
     long long pitch) {
-    constexpr int ROWS = BLOCK / LPS;
-    const int slot = blockIdx.x * ROWS + threadIdx.x / LPS;
-    const int sub = threadIdx.x % LPS;
-    if (slot >= n_rows) return;
+    constexpr int GPW = 64 / LPS;              // streamlines per wave
+    constexpr int ROWS = (BLOCK / 64) * GPW;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPS;
+    const int slot = blockIdx.x * ROWS + (threadIdx.x >> 6) * GPW + grp;
+    const int sub = lane - grp * LPS;
+    if (grp >= GPW || slot >= n_rows) return;
     const int row = proc ? proc[slot] : slot;
     const int g = idx ? idx[row] : row;
     const int r = row_dest ? row_dest[row] : row;
@@ -716,7 +719,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
     const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
     long long pitch) {
-    constexpr int ROWS = BLOCK / LPS;
+    // LPS lanes per streamline, 64 / LPS streamlines per wave (LPS need not be
+    // a power of two: with 12 float4 columns per record a wave serves 5
+    // streamlines on 60 lanes instead of 4 on 48)
+    constexpr int GPW = 64 / LPS;
+    constexpr int ROWS = (BLOCK / 64) * GPW;
     int blk = blockIdx.x;
     if (proc && P.xcd_remap) {
         // workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
@@ -727,9 +734,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
         const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = blk & 7;
         blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blk >> 3);
     }
-    const int slot = blk * ROWS + threadIdx.x / LPS;
-    const int sub = threadIdx.x % LPS;
-    if (slot >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPS;
+    const int slot = blk * ROWS + (threadIdx.x >> 6) * GPW + grp;
+    const int sub = lane - grp * LPS;
+    if (grp >= GPW || slot >= n_rows) return;
     const int row = proc ? proc[slot] : slot;
     const int g = idx ? idx[row] : row;
     const int r = row_dest ? row_dest[row] : row;
@@ -1298,7 +1307,8 @@ static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
                         env->P.radius < 1.0f && vol_bytes < (1ull << 32);
 #define TTL_LAUNCH_STATE(LPS)                                                 \
     do {                                                                      \
-        const dim3 grid((n_rows + (BLOCK / LPS) - 1) / (BLOCK / LPS));        \
+        const int rows_per_block = (BLOCK / 64) * (64 / LPS);                 \
+        const dim3 grid((n_rows + rows_per_block - 1) / rows_per_block);      \
         if (!dedupe)                                                          \
             hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, env->P, \
                                idx, row_dest, proc, n_rows, L, out,           \
@@ -1310,6 +1320,7 @@ static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
     } while (0)
     if (C4 <= 4) TTL_LAUNCH_STATE(4);
     else if (C4 <= 8) TTL_LAUNCH_STATE(8);
+    else if (C4 <= 12) TTL_LAUNCH_STATE(12);
     else if (C4 <= 16) TTL_LAUNCH_STATE(16);
     else TTL_LAUNCH_STATE(32);
 #undef TTL_LAUNCH_STATE
