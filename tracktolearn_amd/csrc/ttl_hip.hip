@@ -641,13 +641,24 @@ __global__ __launch_bounds__(BLOCK) void k_state(
     }
     // previous directions, most recent first, zero padded (np.diff of the
     // stored float32 positions)
+    // previous directions, most recent first, zero padded (np.diff of the
+    // stored float32 positions): one whole segment (3 floats from 6
+    // contiguous ones) per lane and iteration
     float *od = orow + 7 * C;
     const int n_seg = L - 1;
-    for (int f = sub; f < 3 * P.n_dirs; f += LPS) {
-        const int j = f / 3, comp = f - 3 * j;
-        float v = 0.0f;
-        if (j < n_seg) v = h[(L - 1 - j) * 3 + comp] - h[(L - 2 - j) * 3 + comp];
-        od[f] = v;
+    for (int j = sub; j < P.n_dirs; j += LPS) {
+        float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+        if (j < n_seg) {
+            const float *a = h + (L - 2 - j) * 3;   // points L-2-j and L-1-j
+            const float ax = a[0], ay = a[1], az = a[2];
+            const float bx = a[3], by = a[4], bz = a[5];
+            vx = bx - ax;
+            vy = by - ay;
+            vz = bz - az;
+        }
+        od[3 * j + 0] = vx;
+        od[3 * j + 1] = vy;
+        od[3 * j + 2] = vz;
     }
 }
 
@@ -858,13 +869,24 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
         if (!LOOP) break;
     }
 #undef TTL_VOX
+    // previous directions, most recent first, zero padded (np.diff of the
+    // stored float32 positions): one whole segment (3 floats from 6
+    // contiguous ones) per lane and iteration
     float *od = orow + 7 * C;
     const int n_seg = L - 1;
-    for (int f = sub; f < 3 * P.n_dirs; f += LPS) {
-        const int j = f / 3, comp = f - 3 * j;
-        float v = 0.0f;
-        if (j < n_seg) v = h[(L - 1 - j) * 3 + comp] - h[(L - 2 - j) * 3 + comp];
-        od[f] = v;
+    for (int j = sub; j < P.n_dirs; j += LPS) {
+        float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+        if (j < n_seg) {
+            const float *a = h + (L - 2 - j) * 3;   // points L-2-j and L-1-j
+            const float ax = a[0], ay = a[1], az = a[2];
+            const float bx = a[3], by = a[4], bz = a[5];
+            vx = bx - ax;
+            vy = by - ay;
+            vz = bz - az;
+        }
+        od[3 * j + 0] = vx;
+        od[3 * j + 1] = vy;
+        od[3 * j + 2] = vz;
     }
 }
 
