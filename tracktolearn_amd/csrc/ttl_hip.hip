@@ -1468,6 +1468,9 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
     env->stepped = 1;
     env->last_order = order;
     const int *proc = nullptr;
+    // a few thousand streamlines fit the caches in any order: stop paying the
+    // two compaction launches for the processing order in the episode's tail
+    if (env->use_proc && n_active < 8192) env->use_proc = 0;
     if (env->use_proc) {
         // next step's processing order: this one, compacted in its own order
         // and renumbered with the survivors' new row ids

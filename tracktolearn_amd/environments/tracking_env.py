@@ -253,12 +253,16 @@ class TrackingEnvironment(BaseEnv):
         return state, reward, done, info
 
     def _row_dest_view(self, n):
-        from ctypes import byref, c_int32, c_void_p
-        idx_p, dest_p, length = c_void_p(), c_void_p(), c_int32()
-        _lib.check(self._lib.ttl_env_view(
-            self._handle, byref(idx_p), byref(dest_p), byref(length)),
-            'ttl_env_view')
-        off = dest_p.value - self._buf_ws.data_ptr()
+        """int32 view of the library's active-row -> state-row map."""
+        off = getattr(self, '_row_dest_off', None)
+        if off is None or self._row_dest_handle is not self._handle:
+            from ctypes import byref, c_int32, c_void_p
+            idx_p, dest_p, length = c_void_p(), c_void_p(), c_int32()
+            _lib.check(self._lib.ttl_env_view(
+                self._handle, byref(idx_p), byref(dest_p), byref(length)),
+                'ttl_env_view')
+            off = self._row_dest_off = dest_p.value - self._buf_ws.data_ptr()
+            self._row_dest_handle = self._handle
         return self._buf_ws[off:off + 4 * n].view(torch.int32)
 
     def harvest(self):
