@@ -79,6 +79,7 @@ struct EnvParams {
     uint8_t *dones;
     // workspace
     uint8_t *stop;     // [n_max] 1 = stopped in the last step
+    float *head;       // [n_max][4] newest point of every active row (row order)
     int *rank;         // [n_max] survivors before this row inside its block
     int *surv_pos;     // [n_max] position among survivors, -1 if stopped
     int *row_dest;     // [n_max] state row written for this active row
@@ -422,6 +423,9 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
             reward_out[i] = rew;
         }
         P.stop[i] = stop ? 1 : 0;
+        // newest point, in row order: the state gather reads it without the
+        // idx -> history indirection (one dependent memory round trip less)
+        *reinterpret_cast<float4 *>(P.head + 4 * (size_t)i) = float4{p2x, p2y, p2z, 0.0f};
     }
 
     block_survivor_ranks(P, i, active, active && !stop);
@@ -754,9 +758,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     const int g = idx ? idx[row] : row;
     const int r = row_dest ? row_dest[row] : row;
     const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
-    float px = h[(L - 1) * 3 + 0];
-    float py = h[(L - 1) * 3 + 1];
-    float pz = h[(L - 1) * 3 + 2];
+    float px, py, pz;
+    if (idx) {      // a step: k_advance left the new point in row order
+        const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
+        px = hp.x;
+        py = hp.y;
+        pz = hp.z;
+    } else {        // reset: the seed
+        px = h[(L - 1) * 3 + 0];
+        py = h[(L - 1) * 3 + 1];
+        pz = h[(L - 1) * 3 + 2];
+    }
     float *orow = out + (size_t)r * (size_t)pitch;
     const int C = P.n_coef;
     const int C4 = P.coef_pitch >> 2;
@@ -1104,6 +1116,7 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     size_t b = 0;
     b += align_up(n, 256);                    // stop
     b += 6 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest, proc_rank, proc x2
+    b += align_up(n * 4 * sizeof(float), 256); // head
     b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
     return b;
@@ -1216,6 +1229,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.proc_counts = (int *)w;     w += align_up(nb * sizeof(int), 256);
     e->proc[0] = (int *)w;        w += align_up(n * sizeof(int), 256);
     e->proc[1] = (int *)w;        w += align_up(n * sizeof(int), 256);
+    P.head = (float *)w;          w += align_up(n * 4 * sizeof(float), 256);
     P.counts = (int *)w;
     e->length = 0;
     e->n_active = 0;
