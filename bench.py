@@ -297,6 +297,10 @@ def main():
                 'bound': 'hbm', 'kernel': 'k_state_dd<12,4,false>',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                # memory-side view of the same launch (PMC bytes / duration)
+                'traffic_GBs': (traffic / avg_launch_s / 1e9) if traffic else None,
+                'traffic_frac': (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS)
+                if traffic else None,
                 'bytes_per_unit': kern_b,
                 'units_per_launch': units_per_launch,
                 'avg_launch_ms': avg_launch_s * 1e3,
