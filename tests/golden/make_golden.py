@@ -139,7 +139,8 @@ def scripted_actions(rng, state, n_sh, step, wobble):
 
 
 def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
-              wobble, theta=30.0, npv=2, seed=7, state_every=1):
+              wobble, theta=30.0, npv=2, seed=7, state_every=1, aim_centre=False,
+              state_steps=(), keep_history=True):
     sh, mask, pk = synthetic_subject(D)
     aff = np.eye(4, dtype=affine_dtype)
     Vol = ref['MRIDataVolume']
@@ -169,12 +170,19 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
                alignment_weighting=1.0,
                mask_coef=env.stopping_criteria[
                    ref['sc'].StoppingFlags.STOPPING_MASK].mask)
+    if D >= 64:      # 7 MB of float64: the smaller traces already pin it
+        del out['mask_coef']
     state = env.reset(0, N)
     out['state_reset'] = state.numpy().copy()
     step = 0
     done = False
     while not np.all(done):
         a = scripted_actions(rng, state.numpy(), n_sh, step, wobble)
+        if aim_centre and step == 0:
+            # head for the centre of the ball: near-diametral, long chords
+            here = env.streamlines[env.continue_idx, 0].astype(np.float64)
+            a = ((D - 1) / 2.0 - here + 0.3 * rng.standard_normal(here.shape)
+                 ).astype(np.float32)
         idx_before = env.continue_idx.copy()
         next_state, rew, done, info = env.step(a.copy())
         out[f'actions_{step}'] = a
@@ -189,7 +197,7 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
         out[f'flags_{step}'] = env.flags.copy()
         out[f'head_{step}'] = env.streamlines[idx_before, env.length - 1].copy()
         ns = next_state.numpy()
-        if step % state_every == 0 or step < 3:
+        if step % state_every == 0 or step < 3 or step in state_steps:
             out[f'state_{step}'] = ns.copy()
         out[f'state_rowsum_{step}'] = ns.astype(np.float64).sum(axis=1)
         state, not_stopping = env.harvest()
@@ -197,7 +205,10 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
         out[f'lengths_{step}'] = env.lengths.copy()
         step += 1
     out['n_steps'] = step
-    out['streamlines'] = env.streamlines.copy()
+    if keep_history:
+        out['streamlines'] = env.streamlines.copy()
+    else:       # long runs: a float64 checksum per streamline instead
+        out['streamlines_rowsum'] = env.streamlines.astype(np.float64).sum(axis=(1, 2))
     tg = env.get_streamlines()
     out['tract_lengths'] = np.array([len(s) for s in tg.streamlines], np.int64)
     out['tract_points'] = np.concatenate(
@@ -306,6 +317,13 @@ def main():
     run_trace(ref, 'trace_f32_K4_n512', D=16, N=512, K=4, noisy=False,
               affine_dtype=np.float32, reward=False, max_length=60.0,
               wobble=0.15, state_every=1000)
+    # the shipped model's state: K = 100 with streamlines longer than 101
+    # points, so the direction block is full and slides (96^3 volume, as
+    # BASELINE config 2; near-diametral chords)
+    run_trace(ref, 'trace_f64_K100_long', D=96, N=40, K=100, noisy=True,
+              affine_dtype=np.float64, reward=False, max_length=300.0,
+              wobble=0.02, state_every=100000, aim_centre=True,
+              state_steps=(99, 100, 101, 102, 103), keep_history=True)
     # noisy class with float32 affine (HDF5 validation env), reward on
     run_trace(ref, 'trace_f64_K4_f32affine', D=12, N=64, K=4, noisy=True,
               affine_dtype=np.float32, reward=True, max_length=30.0,

@@ -52,7 +52,8 @@ def _env_from_trace(z):
                    reward=bool(z['reward']))
     assert env.max_nb_steps == int(z['max_nb_steps'])
     assert env.step_size == trace_step_size(z)
-    assert np.array_equal(env._mask_coef.cpu().numpy(), z['mask_coef'])
+    if 'mask_coef' in z.files:
+        assert np.array_equal(env._mask_coef.cpu().numpy(), z['mask_coef'])
     return env
 
 
