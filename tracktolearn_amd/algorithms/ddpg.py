@@ -10,7 +10,6 @@ the device.
 import copy
 from collections import defaultdict
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -6,7 +6,6 @@ device resident: the policy reads the state tensor the env kernels wrote,
 actions never visit the host, and the only per-step host traffic is the 8-byte
 survivor count.
 """
-import numpy as np
 import torch
 
 from tracktolearn_amd.utils.torch_utils import get_device

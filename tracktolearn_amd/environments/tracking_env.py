@@ -27,8 +27,7 @@ import torch
 
 from tracktolearn_amd import _lib
 from tracktolearn_amd.environments.env import BaseEnv
-from tracktolearn_amd.environments.stopping_criteria import (
-    StoppingFlags, is_flag_set)
+from tracktolearn_amd.environments.stopping_criteria import StoppingFlags
 from tracktolearn_amd.tractogram import Tractogram
 
 

@@ -13,8 +13,8 @@ import torch
 from tqdm import tqdm
 
 from tracktolearn_amd.algorithms.shared.utils import add_to_means
-from tracktolearn_amd.tractogram import (LazyTractogram, Tractogram,
-                                         TractogramItem, compress_streamline)
+from tracktolearn_amd.tractogram import (LazyTractogram, TractogramItem,
+                                         compress_streamline)
 
 
 class TrkFile:
