@@ -86,6 +86,9 @@ struct EnvParams {
     int *block_counts; // [ceil(n_max/BLOCK)] survivors per block
     int *proc_rank;    // [n_max] rank of a kept slot of the processing order
     int *proc_counts;  // [ceil(n_max/BLOCK)] kept slots per block
+    float *slot_head;  // [n_max][4] per slot of the processing order: newest point, .w = bits of idx[row]
+    int *slot_dest;    // [n_max] per slot of the processing order: row_dest[row]
+    int slot_rec;      // the gather reads the slot records (0: resolves proc -> idx/row_dest/head itself)
     int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
     int *counts;       // {n_continue, n_stopped}
 };
@@ -467,8 +470,17 @@ __global__ __launch_bounds__(BLOCK) void k_restop(EnvParams P,
 __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
                                                   const int *__restrict__ idx,
                                                   int *__restrict__ idx_next,
+                                                  const int *__restrict__ proc,
                                                   int n_active, int n_blocks,
                                                   int order, int n_pts) {
+    if (proc) {
+        // first half of the processing-order compaction (slot order, same
+        // grid): which slots survive, ranked inside their block
+        const int j = blockIdx.x * BLOCK + threadIdx.x;
+        const bool active = j < n_active;
+        const bool keep = active && P.stop[proc[active ? j : 0]] == 0;
+        block_ranks(P.proc_rank, P.proc_counts, j, active, keep);
+    }
     __shared__ int red[2][BLOCK / 64];
     int before = 0, total = 0;
     for (int b = threadIdx.x; b < n_blocks; b += BLOCK) {
@@ -522,16 +534,8 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
 // streamline separately.  Each step proc is compacted (stable, in proc order)
 // and renumbered with the survivors' new row ids.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_proc_count(EnvParams P,
-                                                      const int *__restrict__ proc,
-                                                      int n_active) {
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = j < n_active;
-    const bool keep = active && P.stop[proc[active ? j : 0]] == 0;
-    block_ranks(P.proc_rank, P.proc_counts, j, active, keep);
-}
-
 __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
+                                                        const int *__restrict__ idx,
                                                         const int *__restrict__ proc,
                                                         int *__restrict__ proc_next,
                                                         int n_active, int n_blocks) {
@@ -550,6 +554,13 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
     const int row = proc[j];
     const int pos = P.surv_pos[row];
     if (pos >= 0) proc_next[before + P.proc_rank[j]] = pos;
+    // everything this step's state gather needs to know about slot j, in slot
+    // order: one thread per slot resolves the row indirections here, so the
+    // gather (12 lanes per slot) starts from two coalesced loads
+    float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
+    hp.w = __int_as_float(idx[row]);
+    *reinterpret_cast<float4 *>(P.slot_head + 4 * (size_t)j) = hp;
+    P.slot_dest[j] = P.row_dest[row];
 }
 
 // ---------------------------------------------------------------------------
@@ -718,8 +729,33 @@ __device__ __forceinline__ int clipi(int v, int n) { return min(max(v, 0), n - 1
 // store-issue bound otherwise.
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef v4f v4f_dword_aligned __attribute__((aligned(4)));
+// the value lane-1 holds (DPP row_shr:1).  Only used between the last two
+// lanes of one lane group, which never straddle a 16-lane DPP row for group
+// sizes 4, 8, 12, 16; both lanes are active together.
+__device__ __forceinline__ float from_prev_lane(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+// MERGE_TAIL: when C is not a multiple of 4 the last column holds 1..3 valid
+// floats.  Instead of separate dword stores (one more store instruction per
+// point with a handful of live lanes: the epilogue is bound by the number of
+// store instructions the texture-address unit has to take), the last lane
+// writes the 16 bytes that END at the row's last coefficient, borrowing the
+// leading floats from its left neighbour; the overlap rewrites equal values.
+template <bool MERGE_TAIL>
 __device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
     // (non-temporal stores were measured 33 % slower here: plain stores)
+    if (MERGE_TAIL) {
+        const f4 p{from_prev_lane(a.x), from_prev_lane(a.y), from_prev_lane(a.z),
+                   from_prev_lane(a.w)};
+        const int back = (c + 3 < C) ? 0 : 4 - (C - c);   // 0 (full column), 1..3
+        v4f v{a.x, a.y, a.z, a.w};
+        if (back == 1) v = v4f{p.w, a.x, a.y, a.z};
+        if (back == 2) v = v4f{p.z, p.w, a.x, a.y};
+        if (back == 3) v = v4f{p.y, p.z, p.w, a.x};
+        *reinterpret_cast<v4f_dword_aligned *>(o - back) = v;
+        return;
+    }
     if (c + 3 < C) {
         *reinterpret_cast<v4f_dword_aligned *>(o) = v4f{a.x, a.y, a.z, a.w};
     } else {
@@ -729,7 +765,7 @@ __device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
     }
 }
 
-template <int LPS, int MINW, bool LOOP>
+template <int LPS, int MINW, bool LOOP, bool MERGE_TAIL>
 __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
     const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
@@ -754,12 +790,25 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     const int slot = blk * ROWS + (threadIdx.x >> 6) * GPW + grp;
     const int sub = lane - grp * LPS;
     if (grp >= GPW || slot >= n_rows) return;
-    const int row = proc ? proc[slot] : slot;
-    const int g = idx ? idx[row] : row;
-    const int r = row_dest ? row_dest[row] : row;
-    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
+    int row, g, r;
     float px, py, pz;
-    if (idx) {      // a step: k_advance left the new point in row order
+    const bool slot_records = proc && idx && P.slot_rec;   // a step in processing order
+    if (slot_records) {     // k_proc_scatter resolved row, idx[row], row_dest[row]
+        const float4 hp = *reinterpret_cast<const float4 *>(P.slot_head + 4 * (size_t)slot);
+        px = hp.x;
+        py = hp.y;
+        pz = hp.z;
+        g = __float_as_int(hp.w);
+        r = P.slot_dest[slot];
+        row = 0;
+    } else {
+        row = proc ? proc[slot] : slot;
+        g = idx ? idx[row] : row;
+        r = row_dest ? row_dest[row] : row;
+    }
+    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
+    if (slot_records) {
+    } else if (idx) {      // a step: k_advance left the new point in row order
         const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
         px = hp.x;
         py = hp.y;
@@ -842,9 +891,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
                             ey, dy, ez, dz);
             const f4 b1 = blend4(v000, v001, v010, v011, ey, dy, ez, dz);
             const f4 b2 = blend4(v100, v101, v110, v111, ey, dy, ez, dz);
-            put4(orow + 0 * C + c, lerp4(b1, b2, dx), c, C);
-            put4(orow + 1 * C + c, lerp4(sel4(xup, b2, b1), sel4(xup, b3, b2), dxp), c, C);
-            put4(orow + 4 * C + c, lerp4(sel4(xdn, b0, b1), sel4(xdn, b1, b2), dxm), c, C);
+            put4<MERGE_TAIL>(orow + 0 * C + c, lerp4(b1, b2, dx), c, C);
+            put4<MERGE_TAIL>(orow + 1 * C + c, lerp4(sel4(xup, b2, b1), sel4(xup, b3, b2), dxp), c, C);
+            put4<MERGE_TAIL>(orow + 4 * C + c, lerp4(sel4(xdn, b0, b1), sel4(xdn, b1, b2), dxm), c, C);
         }
         // --- y axis: slices blended over (x, z) ---
         {
@@ -859,8 +908,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
                             ex, dx, ez, dz);
             const f4 b1 = blend4(v000, v001, v100, v101, ex, dx, ez, dz);
             const f4 b2 = blend4(v010, v011, v110, v111, ex, dx, ez, dz);
-            put4(orow + 2 * C + c, lerp4(sel4(yup, b2, b1), sel4(yup, b3, b2), dyp), c, C);
-            put4(orow + 5 * C + c, lerp4(sel4(ydn, b0, b1), sel4(ydn, b1, b2), dym), c, C);
+            put4<MERGE_TAIL>(orow + 2 * C + c, lerp4(sel4(yup, b2, b1), sel4(yup, b3, b2), dyp), c, C);
+            put4<MERGE_TAIL>(orow + 5 * C + c, lerp4(sel4(ydn, b0, b1), sel4(ydn, b1, b2), dym), c, C);
         }
         // --- z axis: slices blended over (x, y) ---
         {
@@ -875,8 +924,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
                             ex, dx, ey, dy);
             const f4 b1 = blend4(v000, v010, v100, v110, ex, dx, ey, dy);
             const f4 b2 = blend4(v001, v011, v101, v111, ex, dx, ey, dy);
-            put4(orow + 3 * C + c, lerp4(sel4(zup, b2, b1), sel4(zup, b3, b2), dzp), c, C);
-            put4(orow + 6 * C + c, lerp4(sel4(zdn, b0, b1), sel4(zdn, b1, b2), dzm), c, C);
+            put4<MERGE_TAIL>(orow + 3 * C + c, lerp4(sel4(zup, b2, b1), sel4(zup, b3, b2), dzp), c, C);
+            put4<MERGE_TAIL>(orow + 6 * C + c, lerp4(sel4(zdn, b0, b1), sel4(zdn, b1, b2), dzm), c, C);
         }
         if (!LOOP) break;
     }
@@ -1081,7 +1130,7 @@ struct ttl_env {
     int proc_cur;        // which proc buffer is current
     int use_proc;        // a processing order was installed for this episode
     // optional per-kernel timing with HIP events on the caller's stream
-    int state_kernel; // 0: k_state (all 56 corner fetches), else k_state_dd
+    int state_kernel; // 0: k_state (all 56 corner fetches), 3: k_state_dd with scalar tail stores, else k_state_dd
     hipStream_t side;      // carries the early device->host copy of the counts
     hipEvent_t ev_prefix;  // main stream: k_prefix done (counts are final)
     hipEvent_t ev_counts;  // side stream: counts have landed in host memory
@@ -1116,7 +1165,8 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     size_t b = 0;
     b += align_up(n, 256);                    // stop
     b += 6 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest, proc_rank, proc x2
-    b += align_up(n * 4 * sizeof(float), 256); // head
+    b += 2 * align_up(n * 4 * sizeof(float), 256); // head, slot_head
+    b += align_up(n * sizeof(int), 256);      // slot_dest
     b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
     return b;
@@ -1230,6 +1280,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->proc[0] = (int *)w;        w += align_up(n * sizeof(int), 256);
     e->proc[1] = (int *)w;        w += align_up(n * sizeof(int), 256);
     P.head = (float *)w;          w += align_up(n * 4 * sizeof(float), 256);
+    P.slot_head = (float *)w;     w += align_up(n * 4 * sizeof(float), 256);
+    P.slot_dest = (int *)w;       w += align_up(n * sizeof(int), 256);
     P.counts = (int *)w;
     e->length = 0;
     e->n_active = 0;
@@ -1242,6 +1294,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->use_proc = 0;
     e->state_kernel = 4;
     if (const char *v = getenv("TTL_STATE_KERNEL")) e->state_kernel = atoi(v);
+    P.slot_rec = e->state_kernel != 2;
     P.xcd_remap = 1;
     if (const char *v = getenv("TTL_XCD_REMAP")) P.xcd_remap = atoi(v);
     e->side = nullptr;
@@ -1349,8 +1402,12 @@ static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
             hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, env->P, \
                                idx, row_dest, proc, n_rows, L, out,           \
                                (long long)pitch);                             \
+        else if (LPS < 32 && env->P.n_coef >= 4 && env->state_kernel != 3)    \
+            hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32), (LPS < 32)>), grid, dim3(BLOCK), 0, s, \
+                               env->P, idx, row_dest, proc, n_rows, L, out,   \
+                               (long long)pitch);                             \
         else                                                                  \
-            hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32)>), grid, dim3(BLOCK), 0, s, \
+            hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32), false>), grid, dim3(BLOCK), 0, s, \
                                env->P, idx, row_dest, proc, n_rows, L, out,   \
                                (long long)pitch);                             \
     } while (0)
@@ -1458,8 +1515,12 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         HIP_TRY(hipGetLastError());
     }
     prof_mark(env, 1, 0, s);
+    // a few thousand streamlines fit the caches in any order: stop paying for
+    // the processing order in the episode's tail
+    if (env->use_proc && n_active < 8192) env->use_proc = 0;
+    const int *proc = env->use_proc ? env->proc[env->proc_cur] : nullptr;
     hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
-                       n_active, nb, order, n_pts);
+                       proc, n_active, nb, order, n_pts);
     prof_mark(env, 1, 1, s);
     HIP_TRY(hipGetLastError());
     if (host_counts) {
@@ -1481,17 +1542,11 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
     }
     env->stepped = 1;
     env->last_order = order;
-    const int *proc = nullptr;
-    // a few thousand streamlines fit the caches in any order: stop paying the
-    // two compaction launches for the processing order in the episode's tail
-    if (env->use_proc && n_active < 8192) env->use_proc = 0;
-    if (env->use_proc) {
+    if (proc) {
         // next step's processing order: this one, compacted in its own order
-        // and renumbered with the survivors' new row ids
-        proc = env->proc[env->proc_cur];
-        hipLaunchKernelGGL(k_proc_count, dim3(nb), dim3(BLOCK), 0, s, env->P, proc,
-                           n_active);
-        hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, proc,
+        // (ranks from k_prefix) and renumbered with the survivors' new row
+        // ids; plus this step's per-slot records for the gather
+        hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, proc,
                            env->proc[env->proc_cur ^ 1], n_active, nb);
         HIP_TRY(hipGetLastError());
     }
