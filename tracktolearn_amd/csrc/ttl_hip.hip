@@ -1407,7 +1407,7 @@ static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
                                env->P, idx, row_dest, proc, n_rows, L, out,   \
                                (long long)pitch);                             \
         else                                                                  \
-            hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32), false>), grid, dim3(BLOCK), 0, s, \
+            hipLaunchKernelGGL((k_state_dd<LPS, (LPS >= 32 ? 2 : 4), (LPS >= 32), false>), grid, dim3(BLOCK), 0, s, \
                                env->P, idx, row_dest, proc, n_rows, L, out,   \
                                (long long)pitch);                             \
     } while (0)
