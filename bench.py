@@ -294,7 +294,7 @@ def main():
             },
             'streamline_steps': total_units,
             'roofline': {
-                'bound': 'hbm', 'kernel': 'k_state_dd<12,4,false>',
+                'bound': 'hbm', 'kernel': 'k_state_dd<12,4,false,true>',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 # memory-side view of the same launch (PMC bytes / duration)

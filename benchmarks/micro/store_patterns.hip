@@ -89,7 +89,7 @@ template <class F> float timeit(F f, int reps = 20) {
 
 int main() {
     const int n = 246360, C = 45, W = 327;
-    float *out; CK(hipMalloc(&out, (size_t)n * 336 * 4 + 256));
+    float *out; CK(hipMalloc(&out, (size_t)n * 384 * 4 + 256));
     std::vector<int> ident(n), perm(n);
     for (int i = 0; i < n; ++i) ident[i] = perm[i] = i;
     std::mt19937 g(1); std::shuffle(perm.begin(), perm.end(), g);
@@ -106,6 +106,9 @@ int main() {
         rep("cols, pitch 327 (current)", timeit([&] { k_cols<<<g12, BLOCK>>>(d, n, out, 327, C, 1.f); }));
         rep("cols, pitch 328", timeit([&] { k_cols<<<g12, BLOCK>>>(d, n, out, 328, C, 1.f); }));
         rep("linear12 aligned, pitch 328", timeit([&] { k_linear12<<<g12, BLOCK>>>(d, n, out, 328, W, 1.f); }));
+        rep("cols, pitch 352 (line aligned)", timeit([&] { k_cols<<<g12, BLOCK>>>(d, n, out, 352, C, 1.f); }));
+        rep("cols, pitch 384", timeit([&] { k_cols<<<g12, BLOCK>>>(d, n, out, 384, C, 1.f); }));
+        rep("linear12 aligned, pitch 352", timeit([&] { k_linear12<<<g12, BLOCK>>>(d, n, out, 352, W, 1.f); }));
         rep("linear12 aligned, pitch 336", timeit([&] { k_linear12<<<g12, BLOCK>>>(d, n, out, 336, W, 1.f); }));
         rep("peel12, pitch 327", timeit([&] { k_peel12<<<g12, BLOCK>>>(d, n, out, 327, W, 1.f); }));
         rep("linear64 aligned, pitch 328", timeit([&] { k_linear64<<<g64, BLOCK>>>(d, n, out, 328, W, 1.f); }));
