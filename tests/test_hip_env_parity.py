@@ -448,3 +448,64 @@ def test_mask_class_shortcut_changes_no_decision(monkeypatch):
     for thr in (0.1, 0.5, 0.9):
         assert np.array_equal(results[('1', thr)], results[('0', thr)])
         assert np.array_equal(results[('1', thr)], vals < thr)
+
+
+def test_error_paths_return_codes_not_faults():
+    """Call-order and argument errors come back as TTL_ERR_* with a message
+    (C ABI) or as exceptions (host classes); nothing is launched for them and
+    the handle keeps working afterwards."""
+    from tracktolearn_amd import _lib
+    D, N = 12, 64
+    sh, mask, pk = synthetic_subject(D)
+    rng = np.random.RandomState(3)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds, n_dirs=4,
+                   max_length=10.0, reward=False)
+    with pytest.raises(RuntimeError):
+        env.harvest()          # nothing stepped (no handle yet either)
+    env._ensure_capacity(N)    # fresh handle, never reset
+    lib, h = env._lib, env._handle
+    W = env._state_width
+    state = torch.empty((N, W), dtype=torch.float32, device='cuda')
+    acts = torch.randn(N, 3, device='cuda')
+    done = torch.empty(N, dtype=torch.uint8, device='cuda')
+    stream = env._stream()
+    # step before reset
+    rc = lib.ttl_env_step(h, acts.data_ptr(), None, N, 0, state.data_ptr(), W, None,
+                          done.data_ptr(), None, stream)
+    assert rc == -3 and lib.ttl_last_error()
+    # harvest with nothing stepped
+    assert lib.ttl_env_harvest(h, state.data_ptr(), state.data_ptr(), W, stream) == -3
+    with pytest.raises(RuntimeError):
+        env.harvest()
+    s0 = env.reset(0, N)
+    # wrong number of active rows, bad order, pitch narrower than a row, nulls
+    assert lib.ttl_env_step(h, acts.data_ptr(), None, N - 1, 0, state.data_ptr(), W,
+                            None, done.data_ptr(), None, stream) == -1
+    assert lib.ttl_env_step(h, acts.data_ptr(), None, N, 7, state.data_ptr(), W,
+                            None, done.data_ptr(), None, stream) == -1
+    assert lib.ttl_env_step(h, acts.data_ptr(), None, N, 0, state.data_ptr(), W - 1,
+                            None, done.data_ptr(), None, stream) == -1
+    assert lib.ttl_env_step(h, None, None, N, 0, state.data_ptr(), W, None,
+                            done.data_ptr(), None, stream) == -1
+    assert lib.ttl_env_step(None, acts.data_ptr(), None, N, 0, state.data_ptr(), W,
+                            None, done.data_ptr(), None, stream) == -1
+    assert lib.ttl_env_reset(h, s0.data_ptr(), N + 10 ** 6, None, state.data_ptr(), W,
+                             stream) == -1
+    with pytest.raises(ValueError):
+        env.step(np.zeros((N - 1, 3), np.float32))
+    # the failed calls changed nothing: a normal step still matches the oracle
+    from oracle import env_oracle as orc
+    ref = orc.OracleTrackingEnv(sh, mask, seeds, n_dirs=4, theta=30.0,
+                                step_size=env.step_size, max_nb_steps=env.max_nb_steps,
+                                mask_threshold=0.1, peaks=pk, compute_reward=False,
+                                alignment_weighting=1.0)
+    ref.reset(0, N)
+    a = rng.standard_normal((N, 3)).astype(np.float32)
+    ns, _, d, _ = env.step(a.copy())
+    ns_ref, _, d_ref, _ = ref.step(a.copy())
+    assert np.array_equal(d, d_ref) and _close(ns.cpu().numpy(), ns_ref)
+    with pytest.raises(RuntimeError):
+        env.step(a)            # second step without harvest
+    env.harvest()

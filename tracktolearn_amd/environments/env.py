@@ -106,6 +106,13 @@ class BaseEnv(object):
         self._lib = _lib.load()
         self._handle = None
         self._n_max = 0
+        # episode bookkeeping of the concrete envs (nothing tracked yet)
+        self._pending = None
+        self._n_active = 0
+        self._n_total = 0
+        self._cur = 0
+        self.length = 0
+        self.not_stopping = None
         self.load_subject()
 
     # ------------------------------------------------------------------ #
