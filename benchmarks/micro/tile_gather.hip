@@ -122,7 +122,7 @@ template <int TX, int TY, int TZ, int TB>
 __global__ __launch_bounds__(TB) void k_tiled(const char *__restrict__ vol, int X, int Y, int Z,
                                                  const float4 *__restrict__ pos, const int *__restrict__ tile_start,
                                                  const int *__restrict__ slots, int ntx, int nty, int ntz,
-                                                 float rad, float *__restrict__ out) {
+                                                 float rad, float *__restrict__ out, int mode) {
     constexpr int RX = TX + 3, RY = TY + 3, RZ = TZ + 3;
     extern __shared__ __align__(16) char lds[];
     constexpr int MAXS = 256;   // streamline records prefetched per pass
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(TB) void k_tiled(const char *__restrict__ vol, int 
     // consecutive records along z
     constexpr int TOTAL = RX * RY * RZ * C4, NLD = (TOTAL + TB - 1) / TB, BATCH = 8;
 #pragma unroll 1
-    for (int b0 = 0; b0 < NLD; b0 += BATCH) {
+    for (int b0 = 0; b0 < (mode == 1 ? 0 : NLD); b0 += BATCH) {
         f4 tmp[BATCH];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(TB) void k_tiled(const char *__restrict__ vol, int 
         }
     }
     const int lane = threadIdx.x & 63, grp = lane / 12, sub = lane - grp * 12;
-    for (int base = 0; base < cnt; base += MAXS) {
+    for (int base = 0; base < (mode == 2 ? 0 : cnt); base += MAXS) {
     const int m = min(cnt - base, MAXS);
     if (base) __syncthreads();
     if (base == 0) {
@@ -192,6 +192,87 @@ __global__ __launch_bounds__(TB) void k_tiled(const char *__restrict__ vol, int 
 }
 
 
+
+// C: persistent workgroups, one LDS region each, the NEXT tile's records
+// prefetched into registers while the current tile is gathered and stored
+template <int TX, int TY, int TZ, int TB, int WPC>
+__global__ __launch_bounds__(TB, WPC) void k_tiled_persist(
+    const char *__restrict__ vol, int X, int Y, int Z, const float4 *__restrict__ srec,
+    const int *__restrict__ tile_start, const int *__restrict__ tiles, int n_tiles, int nty, int ntz,
+    float rad, float *__restrict__ out) {
+    constexpr int RX = TX + 3, RY = TY + 3, RZ = TZ + 3;
+    constexpr int TOTAL = RX * RY * RZ * C4, NLD = (TOTAL + TB - 1) / TB;
+    constexpr int MAXS = 256;
+    extern __shared__ __align__(16) char lds[];
+    float4 *spos = reinterpret_cast<float4 *>(lds + (size_t)RX * RY * RZ * 192);
+    const int lane = threadIdx.x & 63, grp = lane / 12, sub = lane - grp * 12;
+    f4 tmp[NLD];
+    float4 rec0;
+    int start = 0, cnt = 0, ox = 0, oy = 0, oz = 0;
+    auto prefetch = [&](int j) {
+        const int t = tiles[j];
+        start = tile_start[t];
+        cnt = tile_start[t + 1] - start;
+        const int tz = t % ntz, ty = (t / ntz) % nty, tx = t / (ntz * nty);
+        ox = tx * TX - 1; oy = ty * TY - 1; oz = tz * TZ - 1;
+        rec0 = srec[start + min((int)threadIdx.x, cnt - 1)];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = min(k * TB + (int)threadIdx.x, TOTAL - 1);
+            const int r = e / C4, col = e - r * C4;
+            const int cz = r % RZ, cy = (r / RZ) % RY, cx = r / (RZ * RY);
+            const size_t v = ((size_t)clipi(ox + cx, X) * Y + clipi(oy + cy, Y)) * Z + clipi(oz + cz, Z);
+            tmp[k] = *reinterpret_cast<const f4 *>(vol + v * 192 + col * 16);
+        }
+    };
+    int j = blockIdx.x;
+    if (j >= n_tiles) return;
+    prefetch(j);
+    while (true) {
+        // land the prefetched tile (the previous tile's readers are done: barrier)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = k * TB + threadIdx.x;
+            if (e < TOTAL) *reinterpret_cast<f4 *>(lds + (size_t)e * 16) = tmp[k];
+        }
+        const int c_start = start, c_cnt = cnt, cox = ox, coy = oy, coz = oz;
+        if ((int)threadIdx.x < min(c_cnt, MAXS)) spos[threadIdx.x] = rec0;
+        __syncthreads();
+        const int jn = j + gridDim.x;
+        if (jn < n_tiles) prefetch(jn);      // in flight during the gather below
+        for (int base = 0; base < c_cnt; base += MAXS) {
+            const int m = min(c_cnt - base, MAXS);
+            if (base) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < m; i += TB) spos[i] = srec[c_start + base + i];
+                __syncthreads();
+            }
+            if (grp < 5)
+            for (int s = (threadIdx.x >> 6) * 5 + grp; s < m; s += (TB / 64) * 5) {
+                const float4 hp = spos[s];
+                const int row = __float_as_int(hp.w);
+                const float px = hp.x, py = hp.y, pz = hp.z;
+                float *orow = out + (size_t)row * W;
+                POINT_SETUP(px, py, pz)
+                unsigned xo[4], yo[4], zo[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xo[k] = (unsigned)(clipi(ix - 1 + k, X) - cox) * (RY * RZ * 192u);
+                    yo[k] = (unsigned)(clipi(iy - 1 + k, Y) - coy) * (RZ * 192u);
+                    zo[k] = (unsigned)(clipi(iz - 1 + k, Z) - coz) * 192u;
+                }
+                const unsigned cb = sub * 16u;
+                const int c = sub * 4;
+                GATHER_BODY(FETCH_L)
+                if (sub < K) { float *od = orow + 7 * C + 3 * sub; od[0] = 0.25f; od[1] = 0.25f; od[2] = 0.25f; }
+            }
+        }
+        if (jn >= n_tiles) break;
+        j = jn;
+    }
+}
+
 template <class F> float timeit(F f, int reps = 20) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) f();
@@ -204,7 +285,7 @@ template <class F> float timeit(F f, int reps = 20) {
 
 template <int TX, int TY, int TZ, int TB>
 void run_tiled(const char *d_vol, int D, const std::vector<float4> &pos, const float4 *d_pos, float rad,
-               float *d_out, const std::vector<float> &ref, int n) {
+               float *d_out, const std::vector<float> &ref, int n, int mode = 0) {
     const int ntx = (D + TX - 1) / TX, nty = (D + TY - 1) / TY, ntz = (D + TZ - 1) / TZ, nt = ntx * nty * ntz;
     std::vector<int> tile(n), start(nt + 1, 0), slots(n);
     for (int i = 0; i < n; ++i) {
@@ -226,14 +307,48 @@ void run_tiled(const char *d_vol, int D, const std::vector<float4> &pos, const f
     const size_t lds = (size_t)(TX + 3) * (TY + 3) * (TZ + 3) * 192 + 256 * 16;
     CK(hipFuncSetAttribute((const void *)k_tiled<TX, TY, TZ, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipMemset(d_out, 0, (size_t)n * W * 4));
-    const float ms = timeit([&] { k_tiled<TX, TY, TZ, TB><<<nt, TB, lds>>>(d_vol, D, D, D, d_srec, d_start, d_slots, ntx, nty, ntz, rad, d_out); });
+    const float ms = timeit([&] { k_tiled<TX, TY, TZ, TB><<<nt, TB, lds>>>(d_vol, D, D, D, d_srec, d_start, d_slots, ntx, nty, ntz, rad, d_out, mode); });
     CK(hipGetLastError());
     std::vector<float> got((size_t)n * W);
     CK(hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
     const bool same = memcmp(got.data(), ref.data(), got.size() * 4) == 0;
-    printf("tiled %dx%dx%d block %d: %d tiles (%d non-empty, max %d/tile), LDS %zu KB: %.4f ms  %s\n", TX, TY, TZ, TB, nt, nonempty, maxc,
+    printf("tiled mode %d %dx%dx%d block %d: %d tiles (%d non-empty, max %d/tile), LDS %zu KB: %.4f ms  %s\n", mode, TX, TY, TZ, TB, nt, nonempty, maxc,
            lds / 1024, ms, same ? "bit-identical to direct" : "MISMATCH");
     CK(hipFree(d_start)); CK(hipFree(d_slots)); CK(hipFree(d_srec));
+}
+
+template <int TX, int TY, int TZ, int TB, int WPC>
+void run_persist(const char *d_vol, int D, const std::vector<float4> &pos, float rad,
+                 float *d_out, const std::vector<float> &ref, int n) {
+    const int ntx = (D + TX - 1) / TX, nty = (D + TY - 1) / TY, ntz = (D + TZ - 1) / TZ, nt = ntx * nty * ntz;
+    std::vector<int> tile(n), start(nt + 1, 0), slots(n), tiles;
+    for (int i = 0; i < n; ++i) {
+        auto cl = [&](float p) { int v = (int)fminf(fmaxf(floorf(p), -4.0f), (float)D + 4.0f); return std::min(std::max(v, 0), D - 1); };
+        tile[i] = ((cl(pos[i].x) / TX) * nty + cl(pos[i].y) / TY) * ntz + cl(pos[i].z) / TZ;
+        start[tile[i] + 1]++;
+    }
+    for (int t = 0; t < nt; ++t) { if (start[t + 1] > 0) tiles.push_back(t); start[t + 1] += start[t]; }
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < n; ++i) slots[fill[tile[i]]++] = i;
+    std::vector<float4> srec(n);
+    for (int j = 0; j < n; ++j) { srec[j] = pos[slots[j]]; int r = slots[j]; memcpy(&srec[j].w, &r, 4); }
+    int *d_start, *d_tiles; float4 *d_srec;
+    CK(hipMalloc(&d_start, (nt + 1) * 4)); CK(hipMalloc(&d_tiles, tiles.size() * 4)); CK(hipMalloc(&d_srec, n * 16));
+    CK(hipMemcpy(d_start, start.data(), (nt + 1) * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_srec, srec.data(), n * 16, hipMemcpyHostToDevice));
+    const size_t lds = (size_t)(TX + 3) * (TY + 3) * (TZ + 3) * 192 + 256 * 16;
+    CK(hipFuncSetAttribute((const void *)k_tiled_persist<TX, TY, TZ, TB, WPC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemset(d_out, 0, (size_t)n * W * 4));
+    const int grid = std::min((int)tiles.size(), 256 * WPC);
+    const float ms = timeit([&] { k_tiled_persist<TX, TY, TZ, TB, WPC><<<grid, TB, lds>>>(d_vol, D, D, D, d_srec, d_start, d_tiles, (int)tiles.size(), nty, ntz, rad, d_out); });
+    CK(hipGetLastError());
+    std::vector<float> got((size_t)n * W);
+    CK(hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
+    const bool same = memcmp(got.data(), ref.data(), got.size() * 4) == 0;
+    printf("persistent %dx%dx%d block %d x%d/CU: %zu tiles, grid %d, LDS %zu KB: %.4f ms  %s\n", TX, TY, TZ, TB, WPC, tiles.size(), grid,
+           lds / 1024, ms, same ? "bit-identical to direct" : "MISMATCH");
+    CK(hipFree(d_start)); CK(hipFree(d_tiles)); CK(hipFree(d_srec));
 }
 
 int main() {
@@ -269,9 +384,16 @@ int main() {
     printf("direct, brick-sorted order: %.4f ms\n", ms);
     run_tiled<4, 4, 4, 256>(d_vol, D, pos, d_pos, rad, d_out, ref, n);
     run_tiled<4, 4, 4, 512>(d_vol, D, pos, d_pos, rad, d_out, ref, n);
+    run_tiled<4, 4, 4, 512>(d_vol, D, pos, d_pos, rad, d_out, ref, n, 1);
+    run_tiled<4, 4, 4, 512>(d_vol, D, pos, d_pos, rad, d_out, ref, n, 2);
+    run_tiled<4, 4, 4, 1024>(d_vol, D, pos, d_pos, rad, d_out, ref, n);
     run_tiled<4, 4, 2, 256>(d_vol, D, pos, d_pos, rad, d_out, ref, n);
     run_tiled<4, 4, 8, 512>(d_vol, D, pos, d_pos, rad, d_out, ref, n);
     run_tiled<2, 4, 4, 256>(d_vol, D, pos, d_pos, rad, d_out, ref, n);
+    run_persist<4, 4, 4, 1024, 1>(d_vol, D, pos, rad, d_out, ref, n);
+    run_persist<4, 4, 4, 512, 2>(d_vol, D, pos, rad, d_out, ref, n);
+    run_persist<4, 4, 4, 512, 1>(d_vol, D, pos, rad, d_out, ref, n);
+    run_persist<4, 4, 8, 1024, 1>(d_vol, D, pos, rad, d_out, ref, n);
     CK(hipDeviceSynchronize());
     return 0;
 }
