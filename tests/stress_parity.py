@@ -4,7 +4,7 @@ random configurations of the HIP env against the CPU oracle, run to
 exhaustion, looking for rare decision mismatches (curvature threshold band,
 mask-class margin, border folding, processing order).
 
-    python benchmarks/stress_parity.py [n_configs] [seed]
+    python tests/stress_parity.py [n_configs] [seed]
 """
 import os
 import sys
