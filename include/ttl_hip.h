@@ -242,6 +242,26 @@ int ttl_scripted_actions(const float *state, int64_t state_pitch,
                          int32_t n, uint32_t seed, uint32_t step, float wobble,
                          float *actions_out, void *hip_stream);
 
+/* fODF peaks of an SH volume (replaces the per-voxel Python loop of
+ * TrackToLearn/environments/env.py:405-432: sh_to_sf_matrix + get_maximas per
+ * voxel, 5 peaks scaled by value / first value).  sh: [n_voxels][n_coef] f32;
+ * sf_matrix: [n_coef][n_vertices] f32 (SF = SH @ matrix); vertices:
+ * [n_vertices][3] unit vectors of one hemisphere; neighbours:
+ * [n_vertices][degree] vertex indices of the hemisphere graph (rows padded with
+ * the vertex itself).  A direction is a peak if its SF value (values below
+ * absolute_threshold count as 0) is >= all neighbours, > one of them and > 0;
+ * peaks are taken in decreasing order among the max_candidates largest, kept
+ * while value - max(min SF, 0) >= relative_threshold * that of the first and
+ * |cos| to every kept peak <= min_separation_cos.  peaks_out:
+ * [n_voxels][3*npeaks] f32, zeros for voxels whose coefficients sum to 0 and
+ * for missing peaks.  All pointers are device memory. */
+int ttl_peaks_from_sh(const float *sh, int64_t n_voxels, int32_t n_coef,
+                      const float *sf_matrix, const float *vertices,
+                      const int32_t *neighbours, int32_t n_vertices, int32_t degree,
+                      int32_t npeaks, float relative_threshold, float absolute_threshold,
+                      float min_separation_cos, int32_t max_candidates, float *peaks_out,
+                      void *hip_stream);
+
 const char *ttl_last_error(void);
 uint32_t ttl_abi_version(void);
 /* sizeof(ttl_env_desc) as compiled: a binding checks its own struct against it */

@@ -6,9 +6,11 @@ local maxima (scilpy ``get_maximas(data, sphere, B, 0.1, 0)`` = dipy
 ``peak_directions`` with relative threshold 0.1 and 25 degree minimum
 separation), keeps at most 5 peaks, scales them by value / first value and
 stores 15 floats per voxel.  The reference does this voxel by voxel in Python
-(minutes at 145^3); here the projection is one (n_vox x C) @ (C x V) GEMM on
-the matrix cores (PyTorch-ROCm) and maxima / thresholds / separation are
-vectorised torch ops.
+(minutes at 145^3); here it is one
+hand-written HIP kernel (``k_peaks`` in csrc/ttl_hip.hip, C ABI
+``ttl_peaks_from_sh``): one wavefront per voxel, the SH->SF matrix staged in
+LDS, maxima / thresholds / separation decided wave-wide.  (A plain PyTorch
+fp32 restatement lives in tests/ref_peaks.py as the numerics reference.)
 
 PARITY UNPINNED: the reference's sphere is dipy's ``repulsion724`` vertex
 table (data that cannot be regenerated offline) and the basis / peak code is
@@ -101,62 +103,40 @@ def sh_to_sf_matrix(vertices, sh_order):
     return np.stack(rows)
 
 
-@torch.no_grad()
 def peaks_from_sh(sh, npeaks=5, relative_threshold=0.1, absolute_threshold=0.0,
-                  min_separation_angle=25.0, subdivisions=3, chunk=1 << 18,
-                  max_candidates=16):
-    """fODF peaks of an SH volume.
+                  min_separation_angle=25.0, subdivisions=3, max_candidates=16):
+    """fODF peaks of an SH volume on the GPU (``ttl_peaks_from_sh`` /
+    ``k_peaks``: one wavefront per voxel, SH->SF matrix in LDS).
 
-    sh: (X, Y, Z, C) float32 tensor (any device).  Returns (X, Y, Z, 3*npeaks)
-    float32 on the same device: up to ``npeaks`` unit directions sorted by
-    decreasing SF value, each scaled by value / first value; zeros where a
-    voxel has no signal (sum of coefficients == 0, env.py:418) or no peak.
+    sh: (X, Y, Z, C) float32 CUDA tensor.  Returns (X, Y, Z, 3*npeaks) float32
+    on the same device: up to ``npeaks`` unit directions sorted by decreasing
+    SF value, each scaled by value / first value; zeros where a voxel has no
+    signal (sum of coefficients == 0, env.py:418) or no peak.
     """
+    import ctypes as C
+
+    from tracktolearn_amd import _lib
+    lib = _lib.load()                       # raises without the HIP extension
+    if not sh.is_cuda:
+        raise _lib.TTLError('peaks_from_sh needs a CUDA tensor: there is no CPU path')
     dev = sh.device
-    X, Y, Z, C = sh.shape
-    order = int(round((-3 + np.sqrt(1 + 8 * C)) / 2))
+    X, Y, Z, n_coef = sh.shape
+    order = int(round((-3 + np.sqrt(1 + 8 * n_coef)) / 2))
     verts, nbr = hemisphere(subdivisions)
-    B = torch.from_numpy(sh_to_sf_matrix(verts, order).astype(np.float32)).to(dev)
-    V = torch.from_numpy(verts.astype(np.float32)).to(dev)
-    nbr = torch.from_numpy(nbr).to(dev)
-    cos_sep = float(np.cos(np.deg2rad(min_separation_angle)))
-    flat = sh.reshape(-1, C)
-    out = torch.zeros((flat.shape[0], npeaks, 3), dtype=torch.float32, device=dev)
-    K = max_candidates
-    for lo in range(0, flat.shape[0], chunk):
-        part = flat[lo:lo + chunk]
-        sf = part @ B                                            # GEMM (MFMA)
-        sf = torch.where(sf < absolute_threshold, torch.zeros_like(sf), sf)
-        # local maxima on the hemisphere graph: strictly above no neighbour
-        # and above at least one (dipy local_maxima), positive
-        nb_vals = sf[:, nbr]                                     # (n, V, D)
-        is_max = (sf[:, :, None] >= nb_vals).all(dim=2) & \
-            (sf[:, :, None] > nb_vals).any(dim=2) & (sf > 0)
-        cand = torch.where(is_max, sf, torch.full_like(sf, -1.0))
-        vals, idx = cand.topk(K, dim=1)                          # descending
-        valid = vals > 0
-        # relative threshold on (value - min(odf, floor 0))
-        odf_min = sf.min(dim=1, keepdim=True).values.clamp(min=0.0)
-        norm = vals - odf_min
-        valid &= norm >= relative_threshold * norm[:, :1]
-        dirs = V[idx]                                            # (n, K, 3)
-        # greedy minimum-separation pruning, antipodally symmetric
-        kept = torch.zeros_like(valid)
-        for i in range(K):
-            ok = valid[:, i].clone()
-            if i:
-                cosang = (dirs[:, :i] * dirs[:, i:i + 1]).sum(dim=2).abs()
-                ok &= ~((cosang > cos_sep) & kept[:, :i]).any(dim=1)
-            kept[:, i] = ok
-        # first npeaks kept candidates, in order
-        rank = kept.cumsum(dim=1) - 1
-        take = kept & (rank < npeaks)
-        rows = torch.nonzero(take)
-        res = torch.zeros((part.shape[0], npeaks, 3), dtype=torch.float32, device=dev)
-        first = torch.where(valid[:, :1], vals[:, :1], torch.ones_like(vals[:, :1]))
-        scale = vals / first
-        res[rows[:, 0], rank[rows[:, 0], rows[:, 1]]] = \
-            dirs[rows[:, 0], rows[:, 1]] * scale[rows[:, 0], rows[:, 1], None]
-        has_signal = part.sum(dim=1) != 0
-        out[lo:lo + chunk] = res * has_signal[:, None, None]
+    B = torch.from_numpy(
+        np.ascontiguousarray(sh_to_sf_matrix(verts, order), dtype=np.float32)).to(dev)
+    if B.shape[0] != n_coef:
+        raise ValueError(f'{n_coef} coefficients are not a full even SH order')
+    V = torch.from_numpy(np.ascontiguousarray(verts, dtype=np.float32)).to(dev)
+    N = torch.from_numpy(np.ascontiguousarray(nbr, dtype=np.int32)).to(dev)
+    flat = sh.reshape(-1, n_coef).contiguous().to(torch.float32)
+    out = torch.empty((flat.shape[0], 3 * npeaks), dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        _lib.check(lib.ttl_peaks_from_sh(
+            flat.data_ptr(), flat.shape[0], n_coef, B.data_ptr(), V.data_ptr(),
+            N.data_ptr(), V.shape[0], N.shape[1], npeaks,
+            float(relative_threshold), float(absolute_threshold),
+            float(np.cos(np.deg2rad(min_separation_angle))), int(max_candidates),
+            out.data_ptr(), stream), 'ttl_peaks_from_sh')
     return out.reshape(X, Y, Z, 3 * npeaks)
