@@ -509,3 +509,49 @@ def test_error_paths_return_codes_not_faults():
     with pytest.raises(RuntimeError):
         env.step(a)            # second step without harvest
     env.harvest()
+
+
+def test_episode_on_a_non_default_stream():
+    """Everything is ordered on the caller's stream (torch's current stream):
+    a whole device-resident episode of 20 000 streamlines issued inside a
+    `torch.cuda.stream(...)` block, with the sorted processing order on,
+    tracks exactly what the oracle tracks."""
+    from oracle import env_oracle as orc
+    from tracktolearn_amd.environments import TrackingEnvironment
+    saved = TrackingEnvironment.SPATIAL_ORDER_MIN
+    TrackingEnvironment.SPATIAL_ORDER_MIN = 1
+    try:
+        D, N = 20, 20000
+        sh, mask, pk = synthetic_subject(D)
+        rng = np.random.RandomState(5)
+        vox = np.argwhere(mask)
+        seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds,
+                           n_dirs=4, max_length=25.0, reward=False)
+            state = env.reset(0, N)
+            recorded = []
+            step = 0
+            while env._n_active:
+                a = env.scripted_actions(state, step, 9, 0.2)
+                recorded.append((a.clone(), env._n_active))
+                env.step_device(a)
+                state, _ = env.harvest()
+                step += 1
+            flags, lengths, lines = env.flags, env.lengths, env.streamlines
+        ref = orc.OracleTrackingEnv(sh, mask, seeds, n_dirs=4, theta=30.0,
+                                    step_size=env.step_size, max_nb_steps=env.max_nb_steps,
+                                    mask_threshold=0.1, peaks=pk, compute_reward=False,
+                                    alignment_weighting=1.0)
+        ref.reset(0, N)
+        for a, n in recorded:
+            assert len(ref.continue_idx) == n
+            ref.step(a.cpu().numpy())
+            ref.harvest()
+        assert len(ref.continue_idx) == 0
+        assert np.array_equal(flags, ref.flags)
+        assert np.array_equal(lengths, ref.lengths)
+        assert np.array_equal(lines, ref.streamlines)
+    finally:
+        TrackingEnvironment.SPATIAL_ORDER_MIN = saved
