@@ -13,8 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = [os.path.join(HERE, 'ttl_hip.hip')]
-HEADERS = [os.path.join(ROOT, 'include', 'ttl_hip.h')]
+SOURCES = [os.path.join(HERE, 'ttl_hip.hip'), os.path.join(HERE, 'ttl_peaks.hip')]
+HEADERS = [os.path.join(ROOT, 'include', 'ttl_hip.h'),
+           os.path.join(HERE, 'ttl_internal.h')]
 OUTPUT = os.path.join(PKG, 'libttl_hip.so')
 
 FLAGS = [
@@ -46,7 +47,7 @@ def up_to_date():
 def build(force=False, verbose=True):
     if not force and up_to_date():
         return OUTPUT
-    cmd = [find_hipcc()] + FLAGS + ['-I', os.path.join(ROOT, 'include')] + \
+    cmd = [find_hipcc()] + FLAGS + ['-I', os.path.join(ROOT, 'include'), '-I', HERE] + \
         SOURCES + ['-o', OUTPUT]
     if verbose:
         print(' '.join(cmd), flush=True)

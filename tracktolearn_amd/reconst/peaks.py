@@ -7,7 +7,7 @@ local maxima (scilpy ``get_maximas(data, sphere, B, 0.1, 0)`` = dipy
 separation), keeps at most 5 peaks, scales them by value / first value and
 stores 15 floats per voxel.  The reference does this voxel by voxel in Python
 (minutes at 145^3); here it is one
-hand-written HIP kernel (``k_peaks`` in csrc/ttl_hip.hip, C ABI
+hand-written HIP kernel (``k_peaks`` in csrc/ttl_peaks.hip, C ABI
 ``ttl_peaks_from_sh``): one wavefront per voxel, the SH->SF matrix staged in
 LDS, maxima / thresholds / separation decided wave-wide.  (A plain PyTorch
 fp32 restatement lives in tests/ref_peaks.py as the numerics reference.)
