@@ -49,48 +49,6 @@ namespace {
 
 constexpr int BLOCK = TTL_BLOCK;
 
-// Device-side view of the environment (a flat copy of the descriptor).
-struct EnvParams {
-    int mode;
-    int sh_dim[3];
-    int n_coef;
-    int coef_pitch;
-    const float *sh;
-    float sh_shift;
-    int mask_dim[3];
-    const double *mask_coef;
-    const uint8_t *mask_cls;  // per-cell class (see k_mask_classes) or null
-    double mask_thr;
-    int peaks_dim[3];
-    const float *peaks;
-    int compute_reward;
-    float align_w;
-    int n_dirs;
-    int max_nb_steps;
-    double step64;
-    float step32;
-    float radius;
-    int curv_enabled;
-    float curv_dot_max;
-    float *hist;
-    int *flags;
-    int *lengths;
-    uint8_t *dones;
-    // workspace
-    uint8_t *stop;     // [n_max] 1 = stopped in the last step
-    float *head;       // [n_max][4] newest point of every active row (row order)
-    int *rank;         // [n_max] survivors before this row inside its block
-    int *surv_pos;     // [n_max] position among survivors, -1 if stopped
-    int *row_dest;     // [n_max] state row written for this active row
-    int *block_counts; // [ceil(n_max/BLOCK)] survivors per block
-    int *proc_rank;    // [n_max] rank of a kept slot of the processing order
-    int *proc_counts;  // [ceil(n_max/BLOCK)] kept slots per block
-    float *slot_head;  // [n_max][4] per slot of the processing order: newest point, .w = bits of idx[row]
-    int *slot_dest;    // [n_max] per slot of the processing order: row_dest[row]
-    int slot_rec;      // the gather reads the slot records (0: resolves proc -> idx/row_dest/head itself)
-    int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
-    int *counts;       // {n_continue, n_stopped}
-};
 
 // ---------------------------------------------------------------------------
 // mask test: scipy.ndimage.map_coordinates(coef, p - 0.5, order=3,
@@ -562,394 +520,6 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
     P.slot_dest[j] = P.row_dest[row];
 }
 
-// ---------------------------------------------------------------------------
-// k_state: LPS lanes per streamline, lane = one float4 column of the padded
-// voxel record, so a group reads each 16B-aligned voxel record as one
-// contiguous coef_pitch*4-byte segment.  7 points x 8 corners accumulate in
-// registers (no cross-lane traffic); the previous-direction block is written
-// by the same lanes.
-// ---------------------------------------------------------------------------
-template <int LPS>
-__global__ __launch_bounds__(BLOCK) void k_state(
-    EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
-    const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
-    long long pitch) {
-    constexpr int GPW = 64 / LPS;              // streamlines per wave
-    constexpr int ROWS = (BLOCK / 64) * GPW;
-    const int lane = threadIdx.x & 63;
-    const int grp = lane / LPS;
-    const int slot = blockIdx.x * ROWS + (threadIdx.x >> 6) * GPW + grp;
-    const int sub = lane - grp * LPS;
-    if (grp >= GPW || slot >= n_rows) return;
-    const int row = proc ? proc[slot] : slot;
-    const int g = idx ? idx[row] : row;
-    const int r = row_dest ? row_dest[row] : row;
-    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
-    const float px = h[(L - 1) * 3 + 0];
-    const float py = h[(L - 1) * 3 + 1];
-    const float pz = h[(L - 1) * 3 + 2];
-    float *orow = out + (size_t)r * (size_t)pitch;
-    const int C = P.n_coef;
-    const int C4 = P.coef_pitch >> 2;
-    const int X = P.sh_dim[0], Y = P.sh_dim[1], Z = P.sh_dim[2];
-    const float4 *vol = reinterpret_cast<const float4 *>(P.sh);
-
-    for (int c4 = sub; c4 < C4; c4 += LPS) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            // neighbourhood point: [0, +x, +y, +z, -x, -y, -z] * radius
-            const float ox = (k == 1) ? P.radius : (k == 4) ? -P.radius : 0.0f;
-            const float oy = (k == 2) ? P.radius : (k == 5) ? -P.radius : 0.0f;
-            const float oz = (k == 3) ? P.radius : (k == 6) ? -P.radius : 0.0f;
-            float x = px + ox, y = py + oy, z = pz + oz;
-            if (P.sh_shift != 0.0f) {
-                x += P.sh_shift;
-                y += P.sh_shift;
-                z += P.sh_shift;
-            }
-            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-            const float dx = x - fx, dy = y - fy, dz = z - fz;
-            // clip the corner indices, not the weights (edge replication);
-            // the float clamp also tames NaN / huge coordinates
-            const int ix0 = (int)fminf(fmaxf(fx, -1.0f), (float)X);
-            const int iy0 = (int)fminf(fmaxf(fy, -1.0f), (float)Y);
-            const int iz0 = (int)fminf(fmaxf(fz, -1.0f), (float)Z);
-            const int xa = min(max(ix0, 0), X - 1), xb = min(max(ix0 + 1, 0), X - 1);
-            const int ya = min(max(iy0, 0), Y - 1), yb = min(max(iy0 + 1, 0), Y - 1);
-            const int za = min(max(iz0, 0), Z - 1), zb = min(max(iz0 + 1, 0), Z - 1);
-            const float ex = 1.0f - dx, ey = 1.0f - dy, ez = 1.0f - dz;
-            const size_t ra = ((size_t)xa * Y + ya) * Z, rb = ((size_t)xa * Y + yb) * Z;
-            const size_t rc = ((size_t)xb * Y + ya) * Z, rd = ((size_t)xb * Y + yb) * Z;
-            // corner order 000,001,010,011,100,101,110,111 (x,y,z bits)
-            const float4 v0 = vol[(ra + za) * C4 + c4];
-            const float4 v1 = vol[(ra + zb) * C4 + c4];
-            const float4 v2 = vol[(rb + za) * C4 + c4];
-            const float4 v3 = vol[(rb + zb) * C4 + c4];
-            const float4 v4 = vol[(rc + za) * C4 + c4];
-            const float4 v5 = vol[(rc + zb) * C4 + c4];
-            const float4 v6 = vol[(rd + za) * C4 + c4];
-            const float4 v7 = vol[(rd + zb) * C4 + c4];
-            const float w0 = (ex * ey) * ez, w1 = (ex * ey) * dz;
-            const float w2 = (ex * dy) * ez, w3 = (ex * dy) * dz;
-            const float w4 = (dx * ey) * ez, w5 = (dx * ey) * dz;
-            const float w6 = (dx * dy) * ez, w7 = (dx * dy) * dz;
-            float4 a;
-#define TTL_ACC(comp)                                                        \
-    a.comp = v0.comp * w0;                                                   \
-    a.comp = a.comp + v1.comp * w1;                                          \
-    a.comp = a.comp + v2.comp * w2;                                          \
-    a.comp = a.comp + v3.comp * w3;                                          \
-    a.comp = a.comp + v4.comp * w4;                                          \
-    a.comp = a.comp + v5.comp * w5;                                          \
-    a.comp = a.comp + v6.comp * w6;                                          \
-    a.comp = a.comp + v7.comp * w7;
-            TTL_ACC(x) TTL_ACC(y) TTL_ACC(z) TTL_ACC(w)
-#undef TTL_ACC
-            const int c = c4 * 4;
-            float *o = orow + k * C + c;
-            if (c + 0 < C) o[0] = a.x;
-            if (c + 1 < C) o[1] = a.y;
-            if (c + 2 < C) o[2] = a.z;
-            if (c + 3 < C) o[3] = a.w;
-        }
-    }
-    // previous directions, most recent first, zero padded (np.diff of the
-    // stored float32 positions)
-    // previous directions, most recent first, zero padded (np.diff of the
-    // stored float32 positions): one whole segment (3 floats from 6
-    // contiguous ones) per lane and iteration
-    float *od = orow + 7 * C;
-    const int n_seg = L - 1;
-    for (int j = sub; j < P.n_dirs; j += LPS) {
-        float vx = 0.0f, vy = 0.0f, vz = 0.0f;
-        if (j < n_seg) {
-            const float *a = h + (L - 2 - j) * 3;   // points L-2-j and L-1-j
-            const float ax = a[0], ay = a[1], az = a[2];
-            const float bx = a[3], by = a[4], bz = a[5];
-            vx = bx - ax;
-            vy = by - ay;
-            vz = bz - az;
-        }
-        od[3 * j + 0] = vx;
-        od[3 * j + 1] = vy;
-        od[3 * j + 2] = vz;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// k_state_dd: same result as k_state (up to float32 summation order, ~1e-7)
-// with the 56 corner fetches of the 7-point stencil deduplicated in registers.
-// For a neighbourhood radius 0 < r < 1 voxel the shifted points (+-r along one
-// axis) sit in the centre cell or in the adjacent one, so along each axis only
-// the slices f-1 .. f+2 are touched and the other two axes keep the centre's
-// 2x2 footprint and weights.  Per axis: B_s = bilinear blend (other two axes)
-// of slice s; centre / plus / minus points are then 1-D lerps of two B_s.
-// Loads: 8 centre-cell voxels + 4 per outer slice that is really needed
-// (f-1 iff the minus point crosses down, f+2 iff the plus point crosses up):
-// 20..32 records per streamline (26 on average) instead of 56.
-// ---------------------------------------------------------------------------
-struct f4 {
-    float x, y, z, w;
-};
-// 16-byte load at a 32-bit byte offset from a wave-uniform base: lets the
-// compiler use the SGPR-base + VGPR-offset addressing form (one VGPR per
-// address instead of two)
-__device__ __forceinline__ f4 ld4(const char *base, unsigned byte_off) {
-    const float4 v = *reinterpret_cast<const float4 *>(base + byte_off);
-    return f4{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ f4 scale4(f4 a, float w) {
-    return f4{a.x * w, a.y * w, a.z * w, a.w * w};
-}
-__device__ __forceinline__ f4 axpy4(f4 acc, f4 a, float w) {  // acc + a*w
-    return f4{acc.x + a.x * w, acc.y + a.y * w, acc.z + a.z * w, acc.w + a.w * w};
-}
-// bilinear blend of 4 records with weights (a0,a1) x (b0,b1)
-__device__ __forceinline__ f4 blend4(f4 v00, f4 v01, f4 v10, f4 v11, float a0,
-                                     float a1, float b0, float b1) {
-    f4 r = scale4(v00, a0 * b0);
-    r = axpy4(r, v01, a0 * b1);
-    r = axpy4(r, v10, a1 * b0);
-    r = axpy4(r, v11, a1 * b1);
-    return r;
-}
-__device__ __forceinline__ f4 lerp4(f4 lo, f4 hi, float d) {
-    return axpy4(scale4(lo, 1.0f - d), hi, d);
-}
-__device__ __forceinline__ f4 sel4(bool c, f4 a, f4 b) {
-    return f4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w};
-}
-__device__ __forceinline__ int clipi(int v, int n) { return min(max(v, 0), n - 1); }
-// store the float4 column c..c+3 of one point's C coefficients (the last
-// column of a padded record may be partial).  State rows are only 4-byte
-// aligned (W = 7C + 3K floats), so the full column goes out as ONE dword-
-// aligned 16-byte store (gfx950 global stores need dword alignment only)
-// instead of four strided dword stores: the row-per-lane-group epilogue is
-// store-issue bound otherwise.
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef v4f v4f_dword_aligned __attribute__((aligned(4)));
-// the value lane-1 holds (DPP row_shr:1).  Only used between the last two
-// lanes of one lane group, which never straddle a 16-lane DPP row for group
-// sizes 4, 8, 12, 16; both lanes are active together.
-__device__ __forceinline__ float from_prev_lane(float v) {
-    return __int_as_float(
-        __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));
-}
-// MERGE_TAIL: when C is not a multiple of 4 the last column holds 1..3 valid
-// floats.  Instead of separate dword stores (one more store instruction per
-// point with a handful of live lanes: the epilogue is bound by the number of
-// store instructions the texture-address unit has to take), the last lane
-// writes the 16 bytes that END at the row's last coefficient, borrowing the
-// leading floats from its left neighbour; the overlap rewrites equal values.
-template <bool MERGE_TAIL>
-__device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
-    // (non-temporal stores were measured 33 % slower here: plain stores)
-    if (MERGE_TAIL) {
-        const f4 p{from_prev_lane(a.x), from_prev_lane(a.y), from_prev_lane(a.z),
-                   from_prev_lane(a.w)};
-        const int back = (c + 3 < C) ? 0 : 4 - (C - c);   // 0 (full column), 1..3
-        v4f v{a.x, a.y, a.z, a.w};
-        if (back == 1) v = v4f{p.w, a.x, a.y, a.z};
-        if (back == 2) v = v4f{p.z, p.w, a.x, a.y};
-        if (back == 3) v = v4f{p.y, p.z, p.w, a.x};
-        *reinterpret_cast<v4f_dword_aligned *>(o - back) = v;
-        return;
-    }
-    if (c + 3 < C) {
-        *reinterpret_cast<v4f_dword_aligned *>(o) = v4f{a.x, a.y, a.z, a.w};
-    } else {
-        if (c + 0 < C) o[0] = a.x;
-        if (c + 1 < C) o[1] = a.y;
-        if (c + 2 < C) o[2] = a.z;
-    }
-}
-
-template <int LPS, int MINW, bool LOOP, bool MERGE_TAIL>
-__global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
-    EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
-    const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
-    long long pitch) {
-    // LPS lanes per streamline, 64 / LPS streamlines per wave (LPS need not be
-    // a power of two: with 12 float4 columns per record a wave serves 5
-    // streamlines on 60 lanes instead of 4 on 48)
-    constexpr int GPW = 64 / LPS;
-    constexpr int ROWS = (BLOCK / 64) * GPW;
-    int blk = blockIdx.x;
-    if (proc && P.xcd_remap) {
-        // workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
-        // share one; speed only, never correctness): give every XCD one
-        // contiguous range of the spatially sorted processing order, so that
-        // a voxel is fetched into ONE XCD's L2 instead of all eight.
-        // Bijective for any grid size (cdna_hip_programming.md, T1).
-        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = blk & 7;
-        blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blk >> 3);
-    }
-    const int lane = threadIdx.x & 63;
-    const int grp = lane / LPS;
-    const int slot = blk * ROWS + (threadIdx.x >> 6) * GPW + grp;
-    const int sub = lane - grp * LPS;
-    if (grp >= GPW || slot >= n_rows) return;
-    int row, g, r;
-    float px, py, pz;
-    const bool slot_records = proc && idx && P.slot_rec;   // a step in processing order
-    if (slot_records) {     // k_proc_scatter resolved row, idx[row], row_dest[row]
-        const float4 hp = *reinterpret_cast<const float4 *>(P.slot_head + 4 * (size_t)slot);
-        px = hp.x;
-        py = hp.y;
-        pz = hp.z;
-        g = __float_as_int(hp.w);
-        r = P.slot_dest[slot];
-        row = 0;
-    } else {
-        row = proc ? proc[slot] : slot;
-        g = idx ? idx[row] : row;
-        r = row_dest ? row_dest[row] : row;
-    }
-    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
-    if (slot_records) {
-    } else if (idx) {      // a step: k_advance left the new point in row order
-        const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
-        px = hp.x;
-        py = hp.y;
-        pz = hp.z;
-    } else {        // reset: the seed
-        px = h[(L - 1) * 3 + 0];
-        py = h[(L - 1) * 3 + 1];
-        pz = h[(L - 1) * 3 + 2];
-    }
-    float *orow = out + (size_t)r * (size_t)pitch;
-    const int C = P.n_coef;
-    const int C4 = P.coef_pitch >> 2;
-    const int X = P.sh_dim[0], Y = P.sh_dim[1], Z = P.sh_dim[2];
-    const char *vol = reinterpret_cast<const char *>(P.sh);
-    const float rad = P.radius;
-
-    // centre / plus / minus coordinates per axis (float32 adds as the
-    // reference's `coords + neighbourhood`), floors and fractions
-    float cxp = px + rad, cxm = px + (-rad);
-    float cyp = py + rad, cym = py + (-rad);
-    float czp = pz + rad, czm = pz + (-rad);
-    if (P.sh_shift != 0.0f) {
-        px += P.sh_shift; py += P.sh_shift; pz += P.sh_shift;
-        cxp += P.sh_shift; cxm += P.sh_shift;
-        cyp += P.sh_shift; cym += P.sh_shift;
-        czp += P.sh_shift; czm += P.sh_shift;
-    }
-    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-    const float dx = px - fx, dy = py - fy, dz = pz - fz;
-    const float ex = 1.0f - dx, ey = 1.0f - dy, ez = 1.0f - dz;
-    const float fxp = floorf(cxp), fxm = floorf(cxm);
-    const float fyp = floorf(cyp), fym = floorf(cym);
-    const float fzp = floorf(czp), fzm = floorf(czm);
-    const float dxp = cxp - fxp, dxm = cxm - fxm;
-    const float dyp = cyp - fyp, dym = cym - fym;
-    const float dzp = czp - fzp, dzm = czm - fzm;
-    // does the plus point sit in the next cell / the minus point in the
-    // previous one?  (0 < r < 1 guarantees one cell at most)
-    const bool xup = fxp > fx, xdn = fxm < fx;
-    const bool yup = fyp > fy, ydn = fym < fy;
-    const bool zup = fzp > fz, zdn = fzm < fz;
-    // the float clamp tames NaN / huge coordinates before the int conversion
-    const int ix = (int)fminf(fmaxf(fx, -4.0f), (float)X + 4.0f);
-    const int iy = (int)fminf(fmaxf(fy, -4.0f), (float)Y + 4.0f);
-    const int iz = (int)fminf(fmaxf(fz, -4.0f), (float)Z + 4.0f);
-    // byte offset of a voxel record = ox[.] + oy[.] + oz[.] (32-bit; the host
-    // guarantees the volume < 4 GiB), slices f-1, f, f+1, f+2 clipped per axis
-    const unsigned rec = (unsigned)C4 * 16u;
-    const unsigned sz = rec, sy = rec * (unsigned)Z, sx = sy * (unsigned)Y;
-    const unsigned x0 = clipi(ix - 1, X) * sx, x1 = clipi(ix, X) * sx,
-                   x2 = clipi(ix + 1, X) * sx, x3 = clipi(ix + 2, X) * sx;
-    const unsigned y0 = clipi(iy - 1, Y) * sy, y1 = clipi(iy, Y) * sy,
-                   y2 = clipi(iy + 1, Y) * sy, y3 = clipi(iy + 2, Y) * sy;
-    const unsigned z0 = clipi(iz - 1, Z) * sz, z1 = clipi(iz, Z) * sz,
-                   z2 = clipi(iz + 1, Z) * sz, z3 = clipi(iz + 2, Z) * sz;
-#define TTL_VOX(xo, yo, zo) ((xo) + (yo) + (zo))
-    // one float4 column per lane when the record fits the lane group (LOOP =
-    // false, the usual case: nothing is hoisted and kept live across columns)
-    for (int c4 = sub; c4 < C4; c4 += LPS) {
-        const unsigned cb = (unsigned)c4 * 16u;
-        // centre cell
-        const f4 v000 = ld4(vol, TTL_VOX(x1, y1, z1) + cb), v001 = ld4(vol, TTL_VOX(x1, y1, z2) + cb);
-        const f4 v010 = ld4(vol, TTL_VOX(x1, y2, z1) + cb), v011 = ld4(vol, TTL_VOX(x1, y2, z2) + cb);
-        const f4 v100 = ld4(vol, TTL_VOX(x2, y1, z1) + cb), v101 = ld4(vol, TTL_VOX(x2, y1, z2) + cb);
-        const f4 v110 = ld4(vol, TTL_VOX(x2, y2, z1) + cb), v111 = ld4(vol, TTL_VOX(x2, y2, z2) + cb);
-        const f4 zero{0.f, 0.f, 0.f, 0.f};
-        const int c = c4 * 4;
-        // outer slices are fetched (and reduced to one blended record at once)
-        // only where a shifted point really reaches them
-        // --- x axis: slices blended over (y, z) ---
-        {
-            f4 b0 = zero, b3 = zero;
-            if (xdn)
-                b0 = blend4(ld4(vol, TTL_VOX(x0, y1, z1) + cb), ld4(vol, TTL_VOX(x0, y1, z2) + cb),
-                            ld4(vol, TTL_VOX(x0, y2, z1) + cb), ld4(vol, TTL_VOX(x0, y2, z2) + cb),
-                            ey, dy, ez, dz);
-            if (xup)
-                b3 = blend4(ld4(vol, TTL_VOX(x3, y1, z1) + cb), ld4(vol, TTL_VOX(x3, y1, z2) + cb),
-                            ld4(vol, TTL_VOX(x3, y2, z1) + cb), ld4(vol, TTL_VOX(x3, y2, z2) + cb),
-                            ey, dy, ez, dz);
-            const f4 b1 = blend4(v000, v001, v010, v011, ey, dy, ez, dz);
-            const f4 b2 = blend4(v100, v101, v110, v111, ey, dy, ez, dz);
-            put4<MERGE_TAIL>(orow + 0 * C + c, lerp4(b1, b2, dx), c, C);
-            put4<MERGE_TAIL>(orow + 1 * C + c, lerp4(sel4(xup, b2, b1), sel4(xup, b3, b2), dxp), c, C);
-            put4<MERGE_TAIL>(orow + 4 * C + c, lerp4(sel4(xdn, b0, b1), sel4(xdn, b1, b2), dxm), c, C);
-        }
-        // --- y axis: slices blended over (x, z) ---
-        {
-            f4 b0 = zero, b3 = zero;
-            if (ydn)
-                b0 = blend4(ld4(vol, TTL_VOX(x1, y0, z1) + cb), ld4(vol, TTL_VOX(x1, y0, z2) + cb),
-                            ld4(vol, TTL_VOX(x2, y0, z1) + cb), ld4(vol, TTL_VOX(x2, y0, z2) + cb),
-                            ex, dx, ez, dz);
-            if (yup)
-                b3 = blend4(ld4(vol, TTL_VOX(x1, y3, z1) + cb), ld4(vol, TTL_VOX(x1, y3, z2) + cb),
-                            ld4(vol, TTL_VOX(x2, y3, z1) + cb), ld4(vol, TTL_VOX(x2, y3, z2) + cb),
-                            ex, dx, ez, dz);
-            const f4 b1 = blend4(v000, v001, v100, v101, ex, dx, ez, dz);
-            const f4 b2 = blend4(v010, v011, v110, v111, ex, dx, ez, dz);
-            put4<MERGE_TAIL>(orow + 2 * C + c, lerp4(sel4(yup, b2, b1), sel4(yup, b3, b2), dyp), c, C);
-            put4<MERGE_TAIL>(orow + 5 * C + c, lerp4(sel4(ydn, b0, b1), sel4(ydn, b1, b2), dym), c, C);
-        }
-        // --- z axis: slices blended over (x, y) ---
-        {
-            f4 b0 = zero, b3 = zero;
-            if (zdn)
-                b0 = blend4(ld4(vol, TTL_VOX(x1, y1, z0) + cb), ld4(vol, TTL_VOX(x1, y2, z0) + cb),
-                            ld4(vol, TTL_VOX(x2, y1, z0) + cb), ld4(vol, TTL_VOX(x2, y2, z0) + cb),
-                            ex, dx, ey, dy);
-            if (zup)
-                b3 = blend4(ld4(vol, TTL_VOX(x1, y1, z3) + cb), ld4(vol, TTL_VOX(x1, y2, z3) + cb),
-                            ld4(vol, TTL_VOX(x2, y1, z3) + cb), ld4(vol, TTL_VOX(x2, y2, z3) + cb),
-                            ex, dx, ey, dy);
-            const f4 b1 = blend4(v000, v010, v100, v110, ex, dx, ey, dy);
-            const f4 b2 = blend4(v001, v011, v101, v111, ex, dx, ey, dy);
-            put4<MERGE_TAIL>(orow + 3 * C + c, lerp4(sel4(zup, b2, b1), sel4(zup, b3, b2), dzp), c, C);
-            put4<MERGE_TAIL>(orow + 6 * C + c, lerp4(sel4(zdn, b0, b1), sel4(zdn, b1, b2), dzm), c, C);
-        }
-        if (!LOOP) break;
-    }
-#undef TTL_VOX
-    // previous directions, most recent first, zero padded (np.diff of the
-    // stored float32 positions): one whole segment (3 floats from 6
-    // contiguous ones) per lane and iteration
-    float *od = orow + 7 * C;
-    const int n_seg = L - 1;
-    for (int j = sub; j < P.n_dirs; j += LPS) {
-        float vx = 0.0f, vy = 0.0f, vz = 0.0f;
-        if (j < n_seg) {
-            const float *a = h + (L - 2 - j) * 3;   // points L-2-j and L-1-j
-            const float ax = a[0], ay = a[1], az = a[2];
-            const float bx = a[3], by = a[4], bz = a[5];
-            vx = bx - ax;
-            vy = by - ay;
-            vz = bz - az;
-        }
-        od[3 * j + 0] = vx;
-        od[3 * j + 1] = vy;
-        od[3 * j + 2] = vz;
-    }
-}
-
 // stopping flags of caller-supplied tails (n_pts points per streamline)
 __global__ __launch_bounds__(BLOCK) void k_probe_flags(
     EnvParams P, const float *__restrict__ tail, int n, int n_pts,
@@ -1383,43 +953,6 @@ int ttl_scripted_actions(const float *state, int64_t state_pitch, int32_t dir_of
     return TTL_OK;
 }
 
-static int launch_state(ttl_env *env, const int *idx, const int *row_dest,
-                        const int *proc, int n_rows, int L, float *out,
-                        int64_t pitch, hipStream_t s) {
-    const int C4 = env->P.coef_pitch >> 2;
-    // the register-deduplicated kernel needs the shifted points to stay
-    // within one cell of the centre: 0 < radius < 1 voxel
-    const size_t vol_bytes = (size_t)env->P.sh_dim[0] * env->P.sh_dim[1] *
-                             env->P.sh_dim[2] * env->P.coef_pitch * sizeof(float);
-    const bool dedupe = env->state_kernel != 0 && env->P.radius > 0.0f &&
-                        env->P.radius < 1.0f && vol_bytes < (1ull << 32);
-#define TTL_LAUNCH_STATE(LPS)                                                 \
-    do {                                                                      \
-        const int rows_per_block = (BLOCK / 64) * (64 / LPS);                 \
-        const dim3 grid((n_rows + rows_per_block - 1) / rows_per_block);      \
-        if (!dedupe)                                                          \
-            hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, env->P, \
-                               idx, row_dest, proc, n_rows, L, out,           \
-                               (long long)pitch);                             \
-        else if (LPS < 32 && env->P.n_coef >= 4 && env->state_kernel != 3)    \
-            hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32), (LPS < 32)>), grid, dim3(BLOCK), 0, s, \
-                               env->P, idx, row_dest, proc, n_rows, L, out,   \
-                               (long long)pitch);                             \
-        else                                                                  \
-            hipLaunchKernelGGL((k_state_dd<LPS, (LPS >= 32 ? 2 : 4), (LPS >= 32), false>), grid, dim3(BLOCK), 0, s, \
-                               env->P, idx, row_dest, proc, n_rows, L, out,   \
-                               (long long)pitch);                             \
-    } while (0)
-    if (C4 <= 4) TTL_LAUNCH_STATE(4);
-    else if (C4 <= 8) TTL_LAUNCH_STATE(8);
-    else if (C4 <= 12) TTL_LAUNCH_STATE(12);
-    else if (C4 <= 16) TTL_LAUNCH_STATE(16);
-    else TTL_LAUNCH_STATE(32);
-#undef TTL_LAUNCH_STATE
-    HIP_TRY(hipGetLastError());
-    return TTL_OK;
-}
-
 int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
                   const int32_t *processing_order, float *state_out,
                   int64_t state_pitch, void *hip_stream) {
@@ -1448,8 +981,9 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
     if (env->use_proc)
         HIP_TRY(hipMemcpyAsync(env->proc[0], processing_order, (size_t)n * sizeof(int32_t),
                                hipMemcpyDeviceToDevice, s));
-    return launch_state(env, nullptr, nullptr, env->use_proc ? env->proc[0] : nullptr,
-                        n, 1, state_out, state_pitch, s);
+    return ttl_detail_launch_state(env->P, env->state_kernel, nullptr, nullptr,
+                                   env->use_proc ? env->proc[0] : nullptr, n, 1, state_out,
+                                   state_pitch, s);
 }
 
 int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
@@ -1550,8 +1084,8 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         HIP_TRY(hipGetLastError());
     }
     prof_mark(env, 2, 0, s);
-    const int rc = launch_state(env, idx, env->P.row_dest, proc, n_active, n_pts,
-                                state_out, state_pitch, s);
+    const int rc = ttl_detail_launch_state(env->P, env->state_kernel, idx, env->P.row_dest,
+                                           proc, n_active, n_pts, state_out, state_pitch, s);
     prof_mark(env, 2, 1, s);
     return rc;
 }

@@ -4,6 +4,8 @@
 #define TTL_INTERNAL_H
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "ttl_hip.h"
 
 // records the message returned by ttl_last_error() (thread local) and
@@ -19,4 +21,53 @@ int ttl_detail_fail(int code, const char *fmt, ...) __attribute__((format(printf
     } while (0)
 
 constexpr int TTL_BLOCK = 256;   // threads per workgroup of every kernel
+
+// Device-side view of the environment (a flat copy of the descriptor).
+struct EnvParams {
+    int mode;
+    int sh_dim[3];
+    int n_coef;
+    int coef_pitch;
+    const float *sh;
+    float sh_shift;
+    int mask_dim[3];
+    const double *mask_coef;
+    const uint8_t *mask_cls;  // per-cell class (see k_mask_classes) or null
+    double mask_thr;
+    int peaks_dim[3];
+    const float *peaks;
+    int compute_reward;
+    float align_w;
+    int n_dirs;
+    int max_nb_steps;
+    double step64;
+    float step32;
+    float radius;
+    int curv_enabled;
+    float curv_dot_max;
+    float *hist;
+    int *flags;
+    int *lengths;
+    uint8_t *dones;
+    // workspace
+    uint8_t *stop;     // [n_max] 1 = stopped in the last step
+    float *head;       // [n_max][4] newest point of every active row (row order)
+    int *rank;         // [n_max] survivors before this row inside its block
+    int *surv_pos;     // [n_max] position among survivors, -1 if stopped
+    int *row_dest;     // [n_max] state row written for this active row
+    int *block_counts; // [ceil(n_max/BLOCK)] survivors per block
+    int *proc_rank;    // [n_max] rank of a kept slot of the processing order
+    int *proc_counts;  // [ceil(n_max/BLOCK)] kept slots per block
+    float *slot_head;  // [n_max][4] per slot of the processing order: newest point, .w = bits of idx[row]
+    int *slot_dest;    // [n_max] per slot of the processing order: row_dest[row]
+    int slot_rec;      // the gather reads the slot records (0: resolves proc -> idx/row_dest/head itself)
+    int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
+    int *counts;       // {n_continue, n_stopped}
+};
+
+// ttl_state.hip: gathers the state rows of `n_rows` active rows (a step when
+// idx != nullptr, the reset otherwise) on stream s
+int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx,
+                            const int *row_dest, const int *proc, int n_rows, int L,
+                            float *out, int64_t pitch, hipStream_t s);
 #endif
