@@ -140,9 +140,14 @@ def scripted_actions(rng, state, n_sh, step, wobble):
 
 def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
               wobble, theta=30.0, npv=2, seed=7, state_every=1, aim_centre=False,
-              state_steps=(), keep_history=True):
+              state_steps=(), keep_history=True, voxel=1.0, origin=(0.0, 0.0, 0.0),
+              seed_stream=None):
+    if seed_stream is not None:     # a trace that can be (re)generated on its own
+        _SEED_RNG.seed(seed_stream)
     sh, mask, pk = synthetic_subject(D)
     aff = np.eye(4, dtype=affine_dtype)
+    aff[0, 0] = aff[1, 1] = aff[2, 2] = voxel
+    aff[:3, 3] = origin
     Vol = ref['MRIDataVolume']
     subject = (Vol(sh, aff), Vol(mask.astype(np.float32), aff),
                Vol(mask.astype(np.float32), aff),
@@ -167,7 +172,7 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
                step_size_dtype=str(np.asarray(env.step_size).dtype),
                max_nb_steps=env.max_nb_steps, mask_threshold=0.1,
                noisy=noisy, reward=reward, seeds=env.seeds.copy(),
-               alignment_weighting=1.0,
+               alignment_weighting=1.0, affine=aff.copy(),
                mask_coef=env.stopping_criteria[
                    ref['sc'].StoppingFlags.STOPPING_MASK].mask)
     if D >= 64:      # 7 MB of float64: the smaller traces already pin it
@@ -300,10 +305,29 @@ def isolated(ref):
     _save('isolated_functions', out)
 
 
+def extra_traces(ref):
+    """Traces added after the first set; each seeds its own seed stream, so
+    `python make_golden.py extra` regenerates them alone, byte for byte."""
+    # 2 mm isotropic voxels and an origin offset (files-style float64 affine):
+    # pins convert_length_mm2vox / step size / neighbourhood radius in voxels
+    run_trace(ref, 'trace_f64_K4_vox2mm', D=16, N=96, K=4, noisy=True,
+              affine_dtype=np.float64, reward=True, max_length=24.0,
+              wobble=0.1, state_every=2, voxel=2.0, origin=(-16.0, -20.0, -12.0),
+              seed_stream=977)
+    # the same geometry through the training class with a float32 affine
+    run_trace(ref, 'trace_f32_K4_vox2mm', D=16, N=96, K=4, noisy=False,
+              affine_dtype=np.float32, reward=False, max_length=24.0,
+              wobble=0.3, state_every=2, voxel=2.0, origin=(-16.0, -20.0, -12.0),
+              seed_stream=978)
+
+
 def main():
     if not os.path.isdir(REFERENCE):
         sys.exit('reference tree not present; fixtures are committed')
     ref = import_reference()
+    if sys.argv[1:] == ['extra']:
+        extra_traces(ref)
+        return
     isolated(ref)
     # train env, float32 affine -> float32 direction arithmetic, reward on
     run_trace(ref, 'trace_f32_K4_reward', D=12, N=96, K=4, noisy=False,
@@ -328,6 +352,7 @@ def main():
     run_trace(ref, 'trace_f64_K4_f32affine', D=12, N=64, K=4, noisy=True,
               affine_dtype=np.float32, reward=True, max_length=30.0,
               wobble=0.2, state_every=2)
+    extra_traces(ref)
 
 
 if __name__ == '__main__':

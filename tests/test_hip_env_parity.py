@@ -29,12 +29,14 @@ def _dto(*, n_dirs, theta=30.0, max_length, reward, noise=0.0, thr=0.1,
                 target_sh_order=8, noise=noise, fa_map=None)
 
 
-def _hip_env(D, *, noisy, affine_dtype, seeds, **kw):
+def _hip_env(D, *, noisy, affine_dtype, seeds, affine=None, **kw):
     from tracktolearn_amd.datasets.utils import MRIDataVolume as Vol
     from tracktolearn_amd.environments import (NoisyTrackingEnvironment,
                                                TrackingEnvironment)
     sh, mask, pk = synthetic_subject(D)
     aff = np.eye(4, dtype=affine_dtype)
+    if affine is not None:
+        aff = np.asarray(affine).astype(affine_dtype)
     subject = (Vol(sh, aff), Vol(mask.astype(np.float32), aff),
                Vol(mask.astype(np.float32), aff), Vol(pk, aff), None)
     cls = NoisyTrackingEnvironment if noisy else TrackingEnvironment
@@ -47,6 +49,7 @@ def _env_from_trace(z):
     max_length = float(z['max_nb_steps']) * 0.75 + 0.01
     aff = np.float32 if str(z['step_size_dtype']) == 'float32' else np.float64
     env = _hip_env(int(z['D']), noisy=bool(z['noisy']), affine_dtype=aff,
+                   affine=z['affine'] if 'affine' in z.files else None,
                    seeds=z['seeds'], n_dirs=int(z['n_dirs']),
                    theta=float(z['theta']), max_length=max_length,
                    reward=bool(z['reward']))
