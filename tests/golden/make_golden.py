@@ -141,7 +141,7 @@ def scripted_actions(rng, state, n_sh, step, wobble):
 def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
               wobble, theta=30.0, npv=2, seed=7, state_every=1, aim_centre=False,
               state_steps=(), keep_history=True, voxel=1.0, origin=(0.0, 0.0, 0.0),
-              seed_stream=None):
+              seed_stream=None, noise=0.0):
     if seed_stream is not None:     # a trace that can be (re)generated on its own
         _SEED_RNG.seed(seed_stream)
     sh, mask, pk = synthetic_subject(D)
@@ -153,7 +153,7 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
                Vol(mask.astype(np.float32), aff),
                Vol(pk, aff) if pk is not None else None, None)
     dto = dict(dataset_file=None, fa_map=None, n_dirs=K, step_size=0.75,
-               theta=theta, min_length=2.0, max_length=max_length, noise=0.0,
+               theta=theta, min_length=2.0, max_length=max_length, noise=noise,
                npv=npv, rng=np.random.RandomState(seed),
                alignment_weighting=1.0, oracle_bonus=0.0,
                oracle_validator=False, oracle_stopping_criterion=False,
@@ -179,6 +179,11 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
         del out['mask_coef']
     state = env.reset(0, N)
     out['state_reset'] = state.numpy().copy()
+    out['noise'] = np.float64(noise)
+    if noise > 0:       # the generator's state when the first step draws from it
+        st = env.rng.get_state()
+        out['rng_key'], out['rng_pos'] = st[1].copy(), np.int64(st[2])
+        out['rng_has_gauss'], out['rng_cached'] = np.int64(st[3]), np.float64(st[4])
     step = 0
     done = False
     while not np.all(done):
@@ -319,6 +324,11 @@ def extra_traces(ref):
               affine_dtype=np.float32, reward=False, max_length=24.0,
               wobble=0.3, state_every=2, voxel=2.0, origin=(-16.0, -20.0, -12.0),
               seed_stream=978)
+    # sigma > 0: pins how NoisyTrackingEnvironment draws from env_dto['rng']
+    # (one rng.normal(size=(n_active, 3)) per step, noisy_tracking_env.py:74)
+    run_trace(ref, 'trace_f64_K4_sigma', D=12, N=80, K=4, noisy=True,
+              affine_dtype=np.float64, reward=False, max_length=40.0,
+              wobble=0.05, state_every=2, seed_stream=979, noise=0.3)
 
 
 def main():

@@ -7,7 +7,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 TRACES = ['trace_f32_K4_reward', 'trace_f64_K100', 'trace_f32_K4_n512',
           'trace_f64_K4_f32affine', 'trace_f64_K100_long',
-          'trace_f64_K4_vox2mm', 'trace_f32_K4_vox2mm']
+          'trace_f64_K4_vox2mm', 'trace_f32_K4_vox2mm', 'trace_f64_K4_sigma']
 
 
 def synthetic_subject(D, C=45, seed=1234, peaks=True):
@@ -28,6 +28,18 @@ def synthetic_subject(D, C=45, seed=1234, peaks=True):
 def load_trace(name):
     z = np.load(os.path.join(GOLDEN, name + '.npz'))
     return z
+
+
+def trace_noise(z):
+    """(sigma, RandomState in the state the reference's generator had before
+    its first step) of a trace, or (0.0, None)."""
+    sigma = float(z['noise']) if 'noise' in z.files else 0.0
+    if sigma <= 0:
+        return 0.0, None
+    rs = np.random.RandomState(0)
+    rs.set_state(('MT19937', z['rng_key'], int(z['rng_pos']),
+                  int(z['rng_has_gauss']), float(z['rng_cached'])))
+    return sigma, rs
 
 
 def trace_step_size(z):

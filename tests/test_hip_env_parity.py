@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import TRACES, load_trace, synthetic_subject, trace_step_size
+from helpers import (TRACES, load_trace, synthetic_subject, trace_noise,
+                     trace_step_size)
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +53,9 @@ def _env_from_trace(z):
                    affine=z['affine'] if 'affine' in z.files else None,
                    seeds=z['seeds'], n_dirs=int(z['n_dirs']),
                    theta=float(z['theta']), max_length=max_length,
-                   reward=bool(z['reward']))
+                   reward=bool(z['reward']), noise=trace_noise(z)[0])
+    if trace_noise(z)[1] is not None:
+        env.rng.set_state(trace_noise(z)[1].get_state())
     assert env.max_nb_steps == int(z['max_nb_steps'])
     assert env.step_size == trace_step_size(z)
     if 'mask_coef' in z.files:

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from oracle import env_oracle as orc
-from helpers import TRACES, load_trace, synthetic_subject, trace_step_size
+from helpers import (TRACES, load_trace, synthetic_subject, trace_noise,
+                     trace_step_size)
 
 
 def _make_env(z, spline_eval):
@@ -17,7 +18,8 @@ def _make_env(z, spline_eval):
               compute_reward=bool(z['reward']), alignment_weighting=1.0,
               spline_eval=spline_eval)
     if bool(z['noisy']):
-        return orc.OracleNoisyTrackingEnv(sh, mask, z['seeds'], noise=0.0, **kw)
+        sigma, rs = trace_noise(z)
+        return orc.OracleNoisyTrackingEnv(sh, mask, z['seeds'], noise=sigma, rng=rs, **kw)
     return orc.OracleTrackingEnv(sh, mask, z['seeds'], **kw)
 
 
