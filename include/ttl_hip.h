@@ -262,6 +262,18 @@ int ttl_peaks_from_sh(const float *sh, int64_t n_voxels, int32_t n_coef,
                       float min_separation_cos, int32_t max_candidates, float *peaks_out,
                       void *hip_stream);
 
+/* Arc-length resampling of a padded batch of streamlines to nb_points points
+ * each (the oracle's input, TrackToLearn/oracles/oracle.py:52,70: dipy
+ * set_number_of_points).  points: [n] rows of row_pitch floats holding up to
+ * max_len xyz points; lengths32 or lengths64 (exactly one non-null): valid
+ * points per row; out: [n][nb_points][3] f32.  First and last point are kept,
+ * the others sit at arc length k * total / (nb_points - 1) (float64), linearly
+ * interpolated inside their segment.  Device pointers. */
+int ttl_resample_streamlines(const float *points, int64_t row_pitch,
+                             const int32_t *lengths32, const int64_t *lengths64,
+                             int32_t n, int32_t max_len, int32_t nb_points, float *out,
+                             void *hip_stream);
+
 const char *ttl_last_error(void);
 uint32_t ttl_abi_version(void);
 /* sizeof(ttl_env_desc) as compiled: a binding checks its own struct against it */

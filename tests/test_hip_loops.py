@@ -223,8 +223,8 @@ def test_oracle_reward_and_oracle_stopping(tmp_path):
     CPU from the downloaded streamlines with a float32 copy of the network
     (resampler checked against numpy in tests/test_oracle_net.py)."""
     from tracktolearn_amd.environments import TrackingEnvironment
-    from tracktolearn_amd.oracles.oracle import (OracleSingleton,
-                                                 resample_streamlines)
+    from ref_resample import resample_streamlines     # CPU re-derivation
+    from tracktolearn_amd.oracles.oracle import OracleSingleton
     from tracktolearn_amd.oracles.transformer_oracle import (
         TransformerOracle, save_random_checkpoint)
     from tracktolearn_amd.utils.synthetic import (synthetic_seeds,

@@ -33,14 +33,14 @@ def _resample_reference(s, n):
     return out
 
 
-def test_resampler_against_numpy():
-    from tracktolearn_amd.oracles.oracle import resample_streamlines
+def _check_resampler(resample, device):
     rng = np.random.RandomState(0)
     L = 40
     pts = np.cumsum(rng.standard_normal((50, L, 3)) * 0.3 + 0.2, axis=1).astype(np.float32)
     lengths = rng.randint(2, L + 1, 50)
     lengths[:3] = [2, L, 3]
-    got = resample_streamlines(torch.from_numpy(pts), torch.from_numpy(lengths), 128).numpy()
+    got = resample(torch.from_numpy(pts).to(device), torch.from_numpy(lengths).to(device),
+                   128).cpu().numpy()
     for i in range(50):
         want = _resample_reference(pts[i, :lengths[i]], 128)
         assert np.abs(got[i] - want).max() <= 2e-5
@@ -49,6 +49,32 @@ def test_resampler_against_numpy():
     # equally spaced along the curve
     d = np.sqrt((np.diff(got[1].astype(np.float64), axis=0) ** 2).sum(1))
     assert d.std() / d.mean() < 0.15
+    return got
+
+
+def test_reference_resampler_against_numpy():
+    import ref_resample
+    _check_resampler(ref_resample.resample_streamlines, 'cpu')
+
+
+@pytest.mark.gpu
+def test_hip_resampler_against_numpy_and_the_torch_reference():
+    import ref_resample
+    from tracktolearn_amd.oracles.oracle import resample_streamlines
+    got = _check_resampler(resample_streamlines, 'cuda')
+    want = _check_resampler(ref_resample.resample_streamlines, 'cuda')
+    assert np.abs(got - want).max() <= 1e-5
+    # strided rows (a view of a longer history buffer), int32 lengths, ragged
+    rng = np.random.RandomState(3)
+    hist = torch.from_numpy(np.cumsum(rng.standard_normal((3000, 267, 3)) * 0.3, 1)
+                            .astype(np.float32)).cuda()
+    lengths = torch.from_numpy(rng.randint(2, 101, 3000).astype(np.int32)).cuda()
+    view = hist[:, :100]
+    a = resample_streamlines(view, lengths, 128)
+    b = ref_resample.resample_streamlines(view, lengths.long(), 128)
+    assert (a - b).abs().max().item() <= 1e-5
+    with pytest.raises(RuntimeError, match='no CPU'):
+        resample_streamlines(view.cpu(), lengths.cpu(), 128)
 
 
 def test_predict_batching_keeps_the_reference_tail_quirk(tmp_path):
@@ -56,8 +82,10 @@ def test_predict_batching_keeps_the_reference_tail_quirk(tmp_path):
     from tracktolearn_amd.oracles.transformer_oracle import save_random_checkpoint
     ck = save_random_checkpoint(str(tmp_path / 'o.ckpt'), n_head=2, n_layers=1)
     OracleSingleton.reset()
-    oracle = OracleSingleton(ck, torch.device('cpu'), batch_size=8)
-    assert OracleSingleton(ck, torch.device('cpu')) is oracle      # singleton
+    import ref_resample
+    ref = ref_resample.resample_streamlines   # CPU run of the batching logic
+    oracle = OracleSingleton(ck, torch.device('cpu'), batch_size=8, resample=ref)
+    assert OracleSingleton(ck, torch.device('cpu'), resample=ref) is oracle      # singleton
     oracle.batch_size = 8
     rng = np.random.RandomState(1)
     pts = torch.from_numpy(np.cumsum(rng.standard_normal((21, 12, 3)), 1).astype(np.float32))

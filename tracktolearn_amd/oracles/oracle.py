@@ -17,42 +17,44 @@ from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
 
 
 def resample_streamlines(points, lengths, nb_points=128):
-    """Arc-length resampling of a padded batch.
+    """Arc-length resampling of a padded batch on the GPU
+    (``ttl_resample_streamlines`` / ``k_resample``, one wavefront per row).
 
-    points (N, L, 3) float, lengths (N,) number of valid points per row (>= 2)
-    -> (N, nb_points, 3): equally spaced along the polyline, first and last
-    point kept.  This is what ``dipy.tracking.streamline.set_number_of_points``
-    computes (oracle.py:52,70; dipy is absent -> restated from its documented
-    behaviour, parity unpinned): cumulative segment lengths in float64, target
-    arc length k * total / (nb_points - 1), linear interpolation inside the
-    segment that contains it.
+    points (N, L, 3) float32 CUDA tensor, lengths (N,) number of valid points
+    per row (>= 2) -> (N, nb_points, 3) float32: equally spaced along the
+    polyline, first and last point kept.  This is what
+    ``dipy.tracking.streamline.set_number_of_points`` computes (oracle.py:52,70;
+    dipy is absent -> restated from its documented behaviour, parity unpinned):
+    cumulative segment lengths in float64, target arc length
+    k * total / (nb_points - 1), linear interpolation inside the segment that
+    contains it.  (Plain PyTorch restatement: tests/ref_resample.py.)
     """
+    import ctypes as C
+
+    from tracktolearn_amd import _lib
+    lib = _lib.load()
+    if not points.is_cuda:
+        raise _lib.TTLError('resample_streamlines needs CUDA tensors: there is no CPU path')
     n, L, _ = points.shape
-    dev = points.device
-    p = points.double()
-    seg = (p[:, 1:] - p[:, :-1]).norm(dim=2)                    # (N, L-1)
-    steps = torch.arange(L - 1, device=dev)
-    seg = seg * (steps[None, :] < (lengths - 1)[:, None])
-    cum = torch.cat([torch.zeros(n, 1, dtype=torch.float64, device=dev),
-                     seg.cumsum(dim=1)], dim=1)                   # (N, L)
-    total = cum.gather(1, (lengths - 1).clamp(min=0)[:, None])   # (N, 1)
-    k = torch.arange(nb_points, device=dev, dtype=torch.float64)
-    target = total * (k / (nb_points - 1))[None, :]              # (N, nb)
-    # segment j with cum[j] <= t < cum[j+1]
-    j = torch.searchsorted(cum[:, 1:].contiguous(), target.contiguous(),
-                           right=True)
-    j = torch.minimum(j, (lengths - 2).clamp(min=0)[:, None])
-    c0 = cum.gather(1, j)
-    c1 = cum.gather(1, j + 1)
-    denom = (c1 - c0)
-    ratio = torch.where(denom > 0, (target - c0) / denom,
-                        torch.zeros_like(denom))
-    a = p.gather(1, j[:, :, None].expand(-1, -1, 3))
-    b = p.gather(1, (j + 1)[:, :, None].expand(-1, -1, 3))
-    out = a + ratio[:, :, None] * (b - a)
-    last = p.gather(1, (lengths - 1).clamp(min=0)[:, None, None].expand(-1, 1, 3))
-    out[:, -1:] = last
-    return out.to(points.dtype)
+    pts = points.to(torch.float32)
+    if pts.stride(2) != 1 or pts.stride(1) != 3:
+        pts = pts.contiguous()
+    lengths = lengths.to(points.device)
+    if lengths.dtype == torch.int32:
+        l32, l64 = lengths.contiguous(), None
+    else:
+        l32, l64 = None, lengths.to(torch.int64).contiguous()
+    out = torch.empty((n, nb_points, 3), dtype=torch.float32, device=points.device)
+    if n == 0:
+        return out
+    stream = C.c_void_p(torch.cuda.current_stream(points.device).cuda_stream)
+    with torch.cuda.device(points.device):
+        _lib.check(lib.ttl_resample_streamlines(
+            pts.data_ptr(), pts.stride(0),
+            l32.data_ptr() if l32 is not None else None,
+            l64.data_ptr() if l64 is not None else None,
+            n, L, int(nb_points), out.data_ptr(), stream), 'ttl_resample_streamlines')
+    return out
 
 
 class OracleSingleton:
@@ -65,7 +67,7 @@ class OracleSingleton:
             cls._self = super().__new__(cls)
         return cls._self
 
-    def __init__(self, checkpoint: str, device, batch_size=4096):
+    def __init__(self, checkpoint: str, device, batch_size=4096, resample=None):
         ckpt = torch.load(checkpoint, map_location=device, weights_only=True)
         models = {'TransformerOracle': TransformerOracle}
         self.model = models[ckpt['hyper_parameters']['name']] \
@@ -74,6 +76,9 @@ class OracleSingleton:
         self.batch_size = batch_size
         self.device = torch.device(device)
         self.drop_tail = True
+        # the resampler is the HIP kernel; CPU-only tests of the batching
+        # logic inject the PyTorch restatement from tests/
+        self._resample = resample if resample is not None else resample_streamlines
 
     @classmethod
     def reset(cls):
@@ -103,7 +108,7 @@ class OracleSingleton:
         autocast = (torch.autocast('cuda') if self.device.type == 'cuda'
                     else contextlib.nullcontext())
         for lo, hi in spans:
-            data = resample_streamlines(points[lo:hi], lengths[lo:hi], 128)
+            data = self._resample(points[lo:hi], lengths[lo:hi], 128)
             dirs = (data[:, 1:] - data[:, :-1]).float()
             with autocast, torch.no_grad():
                 result[lo:hi] = self.model(dirs).float()
