@@ -155,3 +155,49 @@ def test_config4_shard_first_steps_match_oracle():
                          max_length=300.0, affine=np.float64)
     ref = _oracle(env, subject, noisy=True, K=100, reward=False)
     _first_steps_vs_oracle(env, ref, N, 2, 615)
+
+
+def test_one_million_streamlines_sampled_against_the_oracle():
+    """Maximum size of the named configs on ONE GPU (config 4's 1 048 576
+    streamlines, odd count): device-resident steps, and 4 096 randomly chosen
+    streamlines followed through the CPU oracle with the very same actions
+    (streamlines are independent, so the oracle can track a subset)."""
+    from oracle import env_oracle as orc
+    N, S, K = (1 << 20) + 1, 4096, 4
+    env, subject = _make(96, N, K, noisy=False, reward=False, max_length=200.0)
+    rng = np.random.RandomState(17)
+    sample = np.sort(rng.choice(N, S, replace=False))
+    ref = orc.OracleTrackingEnv(
+        subject[0].data, subject[1].data, env.seeds[sample], n_dirs=K, theta=30.0,
+        step_size=env.step_size, max_nb_steps=env.max_nb_steps, mask_threshold=0.1,
+        peaks=None, compute_reward=False, alignment_weighting=1.0, spline_eval='scipy')
+    state = env.reset(0, N)
+    s_ref = ref.reset(0, S)
+    assert state.shape == (N, 7 * 45 + 3 * K)
+    assert np.abs(state[torch.from_numpy(sample).cuda()].cpu().numpy() - s_ref).max() <= TOL
+    alive = N
+    for step in range(6):
+        ids = env.continue_idx                              # global ids, ascending
+        assert len(ids) == alive and np.all(np.diff(ids) > 0)
+        a = env.scripted_actions(state, step, seed=21, wobble=0.08)
+        want_ids = sample[ref.continue_idx]
+        rows = np.searchsorted(ids, want_ids)
+        assert np.array_equal(ids[rows], want_ids)          # the same streamlines are alive
+        rows_dev = torch.from_numpy(rows).cuda()
+        nstate, _, done, info = env.step_device(a)
+        ns_ref, _, d_ref, _ = ref.step(a[rows_dev].cpu().numpy())
+        dest = info['row_dest'].long()
+        assert np.array_equal(done[rows_dev].cpu().numpy().astype(bool), d_ref)
+        got = nstate[dest[rows_dev]].cpu().numpy()
+        assert np.abs(got - ns_ref).max() <= TOL
+        state, _ = env.harvest()
+        ref.harvest()
+        alive = env._n_active
+        assert alive == int((done == 0).sum())
+    assert alive < N
+    sel = torch.from_numpy(sample).cuda()
+    L = env.length
+    assert np.array_equal(env._buf_streamlines[sel, :L].cpu().numpy(),
+                          ref.streamlines[:, :L])                # bit-identical points
+    assert np.array_equal(env.flags[sample], ref.flags)
+    assert np.array_equal(env.lengths[sample], ref.lengths)
