@@ -130,8 +130,14 @@ class BaseEnv(object):
             (self.subject_id, input_volume, tracking_mask, seeding_mask,
              peaks, reference) = self.dataset[index]
         else:
+            # the runners call load_subject() again right after the constructor
+            # (ttl_track.py:178, train.py:261): the same volumes are already
+            # packed on the device, nothing to redo
+            if getattr(self, '_loaded_subject', None) is self.subject_data:
+                return
             (input_volume, tracking_mask, seeding_mask, peaks,
              reference) = self.subject_data
+            self._loaded_subject = self.subject_data
 
         self.affine_vox2rasmm = input_volume.affine_vox2rasmm
         self.affine_rasmm2vox = np.linalg.inv(self.affine_vox2rasmm)
