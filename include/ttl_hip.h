@@ -216,6 +216,16 @@ int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
                            int32_t n_points, uint8_t *flags_out,
                            void *hip_stream);
 
+/* Replaces the processing order of the state gather between a harvest and the
+ * next step: order[n] (device, int32) is a permutation of the n currently
+ * active rows.  Like the order given to ttl_env_reset it is a scheduling hint
+ * only (which rows a workgroup gathers together; tracking_env.py fixes the
+ * ROW order, not this): results do not depend on it.  The host classes
+ * refresh it every few steps from the streamlines' current positions, because
+ * an order sorted by seed position decays as the streamlines travel. */
+int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
+                                 void *hip_stream);
+
 /* Current continue_idx buffer (device, int32 [n_active]) and, after a step,
  * the active-row -> output-row map (device, int32 [n_active]). */
 int ttl_env_view(ttl_env *env, const int32_t **continue_idx,

@@ -34,6 +34,9 @@ def one(rng, k):
     reward = bool(rng.randint(2))
     N = int(rng.choice([1, 63, 257, 5000, 20000]))
     TrackingEnvironment.SPATIAL_ORDER_MIN = int(rng.choice([1, 1 << 30]))
+    # (own generator: keeps the configurations of earlier logged runs)
+    TrackingEnvironment.SPATIAL_ORDER_REFRESH = int(
+        np.random.RandomState(1000 + k).choice([0, 1, 2, 5, 16]))
     X, Y, Z = shape
     sh = (0.1 * rng.standard_normal((X, Y, Z, C))).astype(np.float32)
     g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing='ij'))

@@ -199,6 +199,8 @@ def test_random_episode_against_oracle(noisy, affine, K, reward, step_mm, kernel
     if kernel == 'sorted':
         from tracktolearn_amd.environments import TrackingEnvironment
         monkeypatch.setattr(TrackingEnvironment, 'SPATIAL_ORDER_MIN', 1)
+        # ... and re-sorted from the current positions every other step
+        monkeypatch.setattr(TrackingEnvironment, 'SPATIAL_ORDER_REFRESH', 2)
     elif kernel is not None:
         monkeypatch.setenv('TTL_STATE_KERNEL', kernel)
     D, N = 24, 4096
@@ -525,7 +527,9 @@ def test_episode_on_a_non_default_stream():
     from oracle import env_oracle as orc
     from tracktolearn_amd.environments import TrackingEnvironment
     saved = TrackingEnvironment.SPATIAL_ORDER_MIN
+    saved_refresh = TrackingEnvironment.SPATIAL_ORDER_REFRESH
     TrackingEnvironment.SPATIAL_ORDER_MIN = 1
+    TrackingEnvironment.SPATIAL_ORDER_REFRESH = 3
     try:
         D, N = 20, 20000
         sh, mask, pk = synthetic_subject(D)
@@ -561,3 +565,4 @@ def test_episode_on_a_non_default_stream():
         assert np.array_equal(lines, ref.streamlines)
     finally:
         TrackingEnvironment.SPATIAL_ORDER_MIN = saved
+        TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved_refresh

@@ -12,6 +12,7 @@ def test_twelve_random_configurations():
     import stress_parity
     from tracktolearn_amd.environments import TrackingEnvironment
     saved = TrackingEnvironment.SPATIAL_ORDER_MIN
+    saved_refresh = TrackingEnvironment.SPATIAL_ORDER_REFRESH
     rng = np.random.RandomState(2024)
     stops = np.zeros(3, np.int64)
     try:
@@ -21,4 +22,5 @@ def test_twelve_random_configurations():
             assert r['worst_state_err'] <= 1e-5
     finally:
         TrackingEnvironment.SPATIAL_ORDER_MIN = saved
+        TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved_refresh
     assert (stops > 0).all()      # mask, length and curvature stops all seen

@@ -1171,6 +1171,20 @@ int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
     return TTL_OK;
 }
 
+int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
+                                 void *hip_stream) {
+    if (!env || !order) return fail(TTL_ERR_INVALID, "ttl_env_set_processing_order: null argument");
+    if (env->length < 1 || env->stepped)
+        return fail(TTL_ERR_STATE, "ttl_env_set_processing_order: between harvest and step only");
+    if (!env->n_exact || n != env->n_active)
+        return fail(TTL_ERR_INVALID, "ttl_env_set_processing_order: n=%d, %d rows are active",
+                    n, env->n_active);
+    HIP_TRY(hipMemcpyAsync(env->proc[env->proc_cur], order, (size_t)n * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    env->use_proc = 1;
+    return TTL_OK;
+}
+
 int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
                  const int32_t **row_dest, int32_t *length) {
     if (!env) return fail(TTL_ERR_INVALID, "ttl_env_view: null handle");
