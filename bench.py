@@ -185,8 +185,8 @@ def main():
     # ---- warm-up on its own episode -------------------------------------
     counter = {'state': env.reset(0, N_ACTOR), 'step': 0, 'resets': 0}
     run_steps(env, args.warmup, seed, counter)
-    # the periodic re-sort of the processing order (every 16 steps) loads its
-    # kernels on first use: do that here, not inside a timed region
+    # exercise the periodic re-sort of the processing order (every 16 steps)
+    # once outside the timed regions
     if env._n_active:
         env._refresh_processing_order(force=True)
     torch.cuda.synchronize()
@@ -217,9 +217,9 @@ def main():
     # K-step region of the contract ----------------------------------------
     ep = None
     if args.whole_episode:
-        # two episodes, the second one reported: the first loads the kernels of
-        # the periodic order refresh for every batch size it meets (a tracking
-        # run pays that once, on its first seed batch)
+        # two episodes, the second one reported (the first one of a process
+        # runs ~30 % slower: allocator growth and first-use effects a tracking
+        # run pays once, on its first seed batch)
         for attempt in range(2):
             state = env.reset(0, N_ACTOR)
             torch.cuda.synchronize()

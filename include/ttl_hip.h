@@ -226,6 +226,12 @@ int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
 int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
                                  void *hip_stream);
 
+/* The same, computed by the library: active rows sorted by the 8^3-voxel brick
+ * of their streamline's newest point (key kernel + radix sort on workspace
+ * memory, no allocation).  Between a harvest and the next step, after the
+ * survivor count has been read back. */
+int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream);
+
 /* Current continue_idx buffer (device, int32 [n_active]) and, after a step,
  * the active-row -> output-row map (device, int32 [n_active]). */
 int ttl_env_view(ttl_env *env, const int32_t **continue_idx,

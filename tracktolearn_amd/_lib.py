@@ -93,6 +93,7 @@ SYMBOLS = {
                                          C.c_int32, C.c_void_p, C.c_void_p]),
     'ttl_env_set_processing_order': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
                                                C.c_void_p]),
+    'ttl_env_refresh_processing_order': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ttl_env_view': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     'ttl_env_profile_begin': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -696,6 +696,8 @@ struct ttl_env {
     int last_n;      // n_active of the pending step
     uint8_t *last_done;  // done_out of the pending step (k_restop updates it)
     int *proc[2];        // processing order of the state gather, double buffered
+    char *order_ws;      // scratch of the in-library order refresh (ttl_order.hip)
+    size_t order_ws_bytes;
     int proc_cur;        // which proc buffer is current
     int use_proc;        // a processing order was installed for this episode
     // optional per-kernel timing with HIP events on the caller's stream
@@ -738,6 +740,7 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     b += align_up(n * sizeof(int), 256);      // slot_dest
     b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
+    b += ttl_detail_order_workspace_bytes(n); // order refresh scratch
     return b;
 }
 
@@ -851,7 +854,9 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.head = (float *)w;          w += align_up(n * 4 * sizeof(float), 256);
     P.slot_head = (float *)w;     w += align_up(n * 4 * sizeof(float), 256);
     P.slot_dest = (int *)w;       w += align_up(n * sizeof(int), 256);
-    P.counts = (int *)w;
+    P.counts = (int *)w;          w += 256;
+    e->order_ws = w;
+    e->order_ws_bytes = ttl_detail_order_workspace_bytes(n);
     e->length = 0;
     e->n_active = 0;
     e->cur = 0;
@@ -1183,6 +1188,20 @@ int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
                            hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
     env->use_proc = 1;
     return TTL_OK;
+}
+
+int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream) {
+    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_refresh_processing_order: null handle");
+    if (env->length < 1 || env->stepped)
+        return fail(TTL_ERR_STATE, "ttl_env_refresh_processing_order: between harvest and step only");
+    if (!env->n_exact)
+        return fail(TTL_ERR_STATE, "ttl_env_refresh_processing_order: survivor count not read back yet");
+    const int *idx = env->cur ? env->d.idx_b : env->d.idx_a;
+    const int rc = ttl_detail_refresh_order(env->P, idx, env->n_active, env->length, env->order_ws,
+                                            env->order_ws_bytes, env->proc[env->proc_cur],
+                                            (hipStream_t)hip_stream);
+    if (rc == TTL_OK) env->use_proc = 1;
+    return rc;
 }
 
 int ttl_env_view(ttl_env *env, const int32_t **continue_idx,

@@ -70,4 +70,10 @@ struct EnvParams {
 int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx,
                             const int *row_dest, const int *proc, int n_rows, int L,
                             float *out, int64_t pitch, hipStream_t s);
+// ttl_order.hip: rows 0..n-1 sorted by the 8^3-voxel brick of their newest
+// point (point L-1 of streamline idx[row]) -> order_out[n]; ws = scratch of
+// ttl_detail_order_workspace_bytes(n_max) bytes
+size_t ttl_detail_order_workspace_bytes(size_t n);
+int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, int L, char *ws,
+                             size_t ws_bytes, int *order_out, hipStream_t s);
 #endif

@@ -1,0 +1,63 @@
+// ttl_order.hip -- processing order of the state gather rebuilt from the
+// streamlines' current positions: a key kernel (8^3-voxel brick of the newest
+// point of every active row) + a 30-bit rocPRIM radix sort of (key, row) pairs
+// on workspace memory.  Scheduling only: results never depend on the order.
+// Part of libttl_hip.so.
+#include "ttl_internal.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+constexpr int BLOCK = TTL_BLOCK;
+
+__global__ __launch_bounds__(BLOCK) void k_order_keys(const float *__restrict__ hist,
+                                                      int max_nb_steps,
+                                                      const int *__restrict__ idx, int n,
+                                                      int L, unsigned *__restrict__ keys,
+                                                      int *__restrict__ rows) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float *p = hist + ((size_t)idx[i] * (size_t)(max_nb_steps + 1) + (size_t)(L - 1)) * 3;
+    unsigned b[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // brick of the voxel the point sits in; NaN and far-away points -> 0 / 1023
+        const float v = floorf((p[a] + 0.5f) * 0.125f);
+        b[a] = (unsigned)fminf(fmaxf(v == v ? v : 0.0f, 0.0f), 1023.0f);
+    }
+    keys[i] = (b[0] << 20) | (b[1] << 10) | b[2];
+    rows[i] = i;
+}
+}  // namespace
+
+size_t ttl_detail_order_workspace_bytes(size_t n) {
+    // keys in/out + rows in (rows out is the processing-order buffer itself),
+    // plus rocPRIM's own scratch (histograms and look-back state: well under
+    // 1 MiB + 4 B per row for the sizes that fit a GPU)
+    return 3 * ((n * 4 + 255) / 256 * 256) + (1u << 20) + n * 4;
+}
+
+int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, int L, char *ws,
+                             size_t ws_bytes, int *order_out, hipStream_t s) {
+    const size_t slab = ((size_t)n * 4 + 255) / 256 * 256;
+    if (ws_bytes < 3 * slab) return fail(TTL_ERR_INVALID, "order refresh: workspace too small");
+    unsigned *keys_in = reinterpret_cast<unsigned *>(ws);
+    unsigned *keys_out = reinterpret_cast<unsigned *>(ws + slab);
+    int *rows_in = reinterpret_cast<int *>(ws + 2 * slab);
+    void *temp = ws + 3 * slab;
+    const size_t temp_avail = ws_bytes - 3 * slab;
+    hipLaunchKernelGGL(k_order_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P.hist,
+                       P.max_nb_steps, idx, n, L, keys_in, rows_in);
+    HIP_TRY(hipGetLastError());
+    size_t need = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, rows_in, order_out,
+                                      (size_t)n, 0u, 30u, s));
+    if (need > temp_avail)
+        return fail(TTL_ERR_INVALID, "order refresh: rocPRIM needs %zu B of scratch, %zu available",
+                    need, temp_avail);
+    HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, rows_in, order_out,
+                                      (size_t)n, 0u, 30u, s));
+    return TTL_OK;
+}

@@ -91,7 +91,7 @@ class TrackingEnvironment(BaseEnv):
     #: the order is rebuilt from the current positions every this many steps
     #: (a streamline crosses an 8-voxel brick in about ten 0.75-voxel steps;
     #: the gather costs 0.72 ns per streamline in fresh order, 1.15 ns once
-    #: the order has decayed); 0 = never
+    #: the order has decayed; measured best of 2/4/8/16/32); 0 = never
     SPATIAL_ORDER_REFRESH = int(os.environ.get('TTL_ORDER_REFRESH', '16'))
 
     def _processing_order(self, points32):
@@ -110,23 +110,17 @@ class TrackingEnvironment(BaseEnv):
 
     def _refresh_processing_order(self, force=False):
         """Every SPATIAL_ORDER_REFRESH steps: re-sort the active rows by where
-        their streamlines are now (ttl_env_set_processing_order).  In steady
-        state one refresh costs about 0.2 ms at 250 k rows (gather, key, sort);
-        the first one in a process also loads the sort kernels (tens of ms),
-        which is why bench.py forces one during its warm-up."""
+        their streamlines are now (``ttl_env_refresh_processing_order``: a key
+        kernel + a radix sort inside the library, on workspace memory)."""
         every = self.SPATIAL_ORDER_REFRESH
         n = self._n_active
-        if n < self.SPATIAL_ORDER_MIN or self._pending is not None:
+        if n < self.SPATIAL_ORDER_MIN or self._pending is not None or \
+                not getattr(self, 'spatial_order', True):
             return
         if not force and (not every or self.length <= 1 or (self.length - 1) % every):
             return
-        heads = self._buf_streamlines[self._idx_view(n).long(), self.length - 1]
-        order = self._processing_order(heads)
-        if order is None:
-            return
-        _lib.check(self._lib.ttl_env_set_processing_order(
-            self._handle, order.data_ptr(), n, self._stream()),
-            'ttl_env_set_processing_order')
+        _lib.check(self._lib.ttl_env_refresh_processing_order(
+            self._handle, self._stream()), 'ttl_env_refresh_processing_order')
 
     def nreset(self, n_seeds: int):
         """N random seeds among all seeds (tracking_env.py:47-89; global
