@@ -149,7 +149,10 @@ void ttl_env_destroy(ttl_env *env);
  * not change any result: it only chooses which streamlines one workgroup of
  * the state gather handles together.  Passing the seeds sorted by spatial
  * brick lets neighbouring workgroups share voxels through L2; the library
- * keeps the order compacted as streamlines stop. */
+ * keeps the order compacted as streamlines stop.  TTL_ORDER_BY_POSITION asks
+ * the library to build that order itself (as ttl_env_refresh_processing_order
+ * does later in the episode). */
+#define TTL_ORDER_BY_POSITION ((const int32_t *)(uintptr_t)1)
 int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
                   const int32_t *processing_order, float *state_out,
                   int64_t state_pitch, void *hip_stream);

@@ -24,6 +24,7 @@ MODE_F64DIR = 1
 MODE_F32NORM = 2
 ORDER_ACTIVE = 0
 ORDER_PARTITION = 1
+ORDER_BY_POSITION = C.c_void_p(1)      # TTL_ORDER_BY_POSITION (ttl_env_reset)
 
 
 class TTLError(RuntimeError):

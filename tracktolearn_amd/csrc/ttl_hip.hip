@@ -983,9 +983,15 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
     env->stepped = 0;
     env->proc_cur = 0;
     env->use_proc = processing_order != nullptr;
-    if (env->use_proc)
+    if (processing_order == TTL_ORDER_BY_POSITION) {
+        // the library's own order: rows sorted by the brick of their seed
+        const int rc = ttl_detail_refresh_order(env->P, d.idx_a, n, 1, env->order_ws,
+                                                env->order_ws_bytes, env->proc[0], s);
+        if (rc != TTL_OK) return rc;
+    } else if (env->use_proc) {
         HIP_TRY(hipMemcpyAsync(env->proc[0], processing_order, (size_t)n * sizeof(int32_t),
                                hipMemcpyDeviceToDevice, s));
+    }
     return ttl_detail_launch_state(env->P, env->state_kernel, nullptr, nullptr,
                                    env->use_proc ? env->proc[0] : nullptr, n, 1, state_out,
                                    state_pitch, s);

@@ -1,6 +1,6 @@
 // ttl_order.hip -- processing order of the state gather rebuilt from the
 // streamlines' current positions: a key kernel (8^3-voxel brick of the newest
-// point of every active row) + a 30-bit rocPRIM radix sort of (key, row) pairs
+// point of every active row) + a rocPRIM radix sort (12-13 key bits) of (key, row) pairs
 // on workspace memory.  Scheduling only: results never depend on the order.
 // Part of libttl_hip.so.
 #include "ttl_internal.h"
@@ -15,28 +15,34 @@ constexpr int BLOCK = TTL_BLOCK;
 __global__ __launch_bounds__(BLOCK) void k_order_keys(const float *__restrict__ hist,
                                                       int max_nb_steps,
                                                       const int *__restrict__ idx, int n,
-                                                      int L, unsigned *__restrict__ keys,
+                                                      int L, int nbx, int nby, int nbz,
+                                                      unsigned *__restrict__ keys,
                                                       int *__restrict__ rows) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float *p = hist + ((size_t)idx[i] * (size_t)(max_nb_steps + 1) + (size_t)(L - 1)) * 3;
+    const int nb[3] = {nbx, nby, nbz};
     unsigned b[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        // brick of the voxel the point sits in; NaN and far-away points -> 0 / 1023
+        // brick of the voxel the point sits in; NaN and far-away points are
+        // clamped into the brick grid
         const float v = floorf((p[a] + 0.5f) * 0.125f);
-        b[a] = (unsigned)fminf(fmaxf(v == v ? v : 0.0f, 0.0f), 1023.0f);
+        b[a] = (unsigned)fminf(fmaxf(v == v ? v : 0.0f, 0.0f), (float)(nb[a] - 1));
     }
-    keys[i] = (b[0] << 20) | (b[1] << 10) | b[2];
+    // dense brick index: as few significant bits (= radix passes) as possible
+    keys[i] = (b[0] * (unsigned)nby + b[1]) * (unsigned)nbz + b[2];
     rows[i] = i;
 }
 }  // namespace
 
 size_t ttl_detail_order_workspace_bytes(size_t n) {
     // keys in/out + rows in (rows out is the processing-order buffer itself),
-    // plus rocPRIM's own scratch (histograms and look-back state: well under
-    // 1 MiB + 4 B per row for the sizes that fit a GPU)
-    return 3 * ((n * 4 + 255) / 256 * 256) + (1u << 20) + n * 4;
+    // plus rocPRIM's own scratch: depending on the path it picks, histograms
+    // and look-back state or a second (key, value) buffer -- 8 B per row and a
+    // few KiB measured; 4 MiB + 24 B per row leaves a wide margin (checked
+    // against rocPRIM's own size query at run time)
+    return 3 * ((n * 4 + 255) / 256 * 256) + (4u << 20) + n * 24;
 }
 
 int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, int L, char *ws,
@@ -48,16 +54,25 @@ int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, int L, c
     int *rows_in = reinterpret_cast<int *>(ws + 2 * slab);
     void *temp = ws + 3 * slab;
     const size_t temp_avail = ws_bytes - 3 * slab;
+    int nb[3];
+    unsigned long long bricks = 1;
+    for (int a = 0; a < 3; ++a) {
+        nb[a] = (P.sh_dim[a] + 7) / 8 + 1;
+        if (nb[a] > 1024) nb[a] = 1024;
+        bricks *= (unsigned long long)nb[a];
+    }
+    unsigned bits = 1;
+    while ((1ull << bits) < bricks) ++bits;
     hipLaunchKernelGGL(k_order_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P.hist,
-                       P.max_nb_steps, idx, n, L, keys_in, rows_in);
+                       P.max_nb_steps, idx, n, L, nb[0], nb[1], nb[2], keys_in, rows_in);
     HIP_TRY(hipGetLastError());
     size_t need = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, rows_in, order_out,
-                                      (size_t)n, 0u, 30u, s));
+                                      (size_t)n, 0u, bits, s));
     if (need > temp_avail)
         return fail(TTL_ERR_INVALID, "order refresh: rocPRIM needs %zu B of scratch, %zu available",
                     need, temp_avail);
     HIP_TRY(rocprim::radix_sort_pairs(temp, need, keys_in, keys_out, rows_in, order_out,
-                                      (size_t)n, 0u, 30u, s));
+                                      (size_t)n, 0u, bits, s));
     return TTL_OK;
 }

@@ -72,10 +72,12 @@ class TrackingEnvironment(BaseEnv):
         ).to(self.device)
         state = torch.empty((n, self._state_width), dtype=torch.float32,
                             device=self.device)
-        order = self._processing_order(seeds32)
+        # batches of SPATIAL_ORDER_MIN rows and more are gathered in a
+        # spatially sorted processing order (built by the library)
+        sort_rows = n >= self.SPATIAL_ORDER_MIN and getattr(self, 'spatial_order', True)
         _lib.check(self._lib.ttl_env_reset(
             self._handle, seeds32.data_ptr(), n,
-            order.data_ptr() if order is not None else None, state.data_ptr(),
+            _lib.ORDER_BY_POSITION if sort_rows else None, state.data_ptr(),
             self._state_width, self._stream()), 'ttl_env_reset')
         self._n_total = n
         self._n_active = n
@@ -93,20 +95,6 @@ class TrackingEnvironment(BaseEnv):
     #: the gather costs 0.72 ns per streamline in fresh order, 1.15 ns once
     #: the order has decayed; measured best of 2/4/8/16/32); 0 = never
     SPATIAL_ORDER_REFRESH = int(os.environ.get('TTL_ORDER_REFRESH', '16'))
-
-    def _processing_order(self, points32):
-        """Rows sorted by the 8^3-voxel brick of their current point (int32
-        permutation on the device), or None for small batches.  A pure
-        scheduling hint for the state gather (see ttl_env_reset): row order and
-        results are unchanged, but streamlines gathered together then share
-        voxels through L2."""
-        n = points32.shape[0]
-        if n < self.SPATIAL_ORDER_MIN or not getattr(self, 'spatial_order', True):
-            return None
-        brick = torch.floor((points32 + 0.5) / 8.0).nan_to_num_(0.0) \
-            .clamp_(0, 1023).to(torch.int64)
-        key = (brick[:, 0] * 1024 + brick[:, 1]) * 1024 + brick[:, 2]
-        return torch.sort(key, stable=True).indices.to(torch.int32)
 
     def _refresh_processing_order(self, force=False):
         """Every SPATIAL_ORDER_REFRESH steps: re-sort the active rows by where
