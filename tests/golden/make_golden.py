@@ -141,7 +141,7 @@ def scripted_actions(rng, state, n_sh, step, wobble):
 def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
               wobble, theta=30.0, npv=2, seed=7, state_every=1, aim_centre=False,
               state_steps=(), keep_history=True, voxel=1.0, origin=(0.0, 0.0, 0.0),
-              seed_stream=None, noise=0.0):
+              seed_stream=None, noise=0.0, thr=0.1):
     if seed_stream is not None:     # a trace that can be (re)generated on its own
         _SEED_RNG.seed(seed_stream)
     sh, mask, pk = synthetic_subject(D)
@@ -158,7 +158,7 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
                alignment_weighting=1.0, oracle_bonus=0.0,
                oracle_validator=False, oracle_stopping_criterion=False,
                oracle_checkpoint=None, scoring_data=None,
-               tractometer_validator=False, binary_stopping_threshold=0.1,
+               tractometer_validator=False, binary_stopping_threshold=thr,
                compute_reward=reward, device=torch.device('cpu'),
                target_sh_order=8)
     cls = ref['NoisyTrackingEnvironment' if noisy else 'TrackingEnvironment']
@@ -170,7 +170,7 @@ def run_trace(ref, name, *, D, N, K, noisy, affine_dtype, reward, max_length,
     out = dict(sh_seed=1234, D=D, C=sh.shape[-1], n_dirs=K, theta=theta,
                step_size=np.asarray(env.step_size),
                step_size_dtype=str(np.asarray(env.step_size).dtype),
-               max_nb_steps=env.max_nb_steps, mask_threshold=0.1,
+               max_nb_steps=env.max_nb_steps, mask_threshold=thr,
                noisy=noisy, reward=reward, seeds=env.seeds.copy(),
                alignment_weighting=1.0, affine=aff.copy(),
                mask_coef=env.stopping_criteria[
@@ -329,6 +329,13 @@ def extra_traces(ref):
     run_trace(ref, 'trace_f64_K4_sigma', D=12, N=80, K=4, noisy=True,
               affine_dtype=np.float64, reward=False, max_length=40.0,
               wobble=0.05, state_every=2, seed_stream=979, noise=0.3)
+    # another angle and mask threshold (every other trace: 30 degrees, 0.1)
+    run_trace(ref, 'trace_f32_K4_theta60_thr05', D=14, N=96, K=4, noisy=False,
+              affine_dtype=np.float32, reward=False, max_length=40.0,
+              wobble=0.6, theta=60.0, thr=0.5, state_every=3, seed_stream=980)
+    run_trace(ref, 'trace_f64_K7_theta20_thr03', D=14, N=96, K=7, noisy=True,
+              affine_dtype=np.float64, reward=True, max_length=40.0,
+              wobble=0.2, theta=20.0, thr=0.3, state_every=3, seed_stream=981)
 
 
 def main():

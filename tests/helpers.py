@@ -7,7 +7,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 TRACES = ['trace_f32_K4_reward', 'trace_f64_K100', 'trace_f32_K4_n512',
           'trace_f64_K4_f32affine', 'trace_f64_K100_long',
-          'trace_f64_K4_vox2mm', 'trace_f32_K4_vox2mm', 'trace_f64_K4_sigma']
+          'trace_f64_K4_vox2mm', 'trace_f32_K4_vox2mm', 'trace_f64_K4_sigma',
+          'trace_f32_K4_theta60_thr05', 'trace_f64_K7_theta20_thr03']
 
 
 def synthetic_subject(D, C=45, seed=1234, peaks=True):

@@ -53,7 +53,8 @@ def _env_from_trace(z):
                    affine=z['affine'] if 'affine' in z.files else None,
                    seeds=z['seeds'], n_dirs=int(z['n_dirs']),
                    theta=float(z['theta']), max_length=max_length,
-                   reward=bool(z['reward']), noise=trace_noise(z)[0])
+                   reward=bool(z['reward']), noise=trace_noise(z)[0],
+                   thr=float(z['mask_threshold']))
     if trace_noise(z)[1] is not None:
         env.rng.set_state(trace_noise(z)[1].get_state())
     assert env.max_nb_steps == int(z['max_nb_steps'])
