@@ -14,10 +14,12 @@
 //                and the wave-ballot survivor ranks for the compaction.
 //   k_prefix   : tracking_env.py:192-195 / 238-241 (stable index compaction:
 //                new_continue_idx = continue_idx[~stopping]).
-//   k_state    : env.py:504-565 (_format_state): 7-point trilinear gather of
-//                the SH volume + last K segment vectors.
+//   k_state*   : env.py:504-565 (_format_state): 7-point trilinear gather of
+//                the SH volume + last K segment vectors -> ttl_state.hip.
 //   k_finish   : tracking_env.py:236 (lengths[stopping_idx] = length).
 //   k_copy_rows: tracking_env.py:245 (state[continue_idx]).
+// Other translation units of libttl_hip.so: ttl_order.hip (processing order of
+// the gather), ttl_peaks.hip (fODF peaks), ttl_resample.hip (oracle input).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
