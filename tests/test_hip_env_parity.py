@@ -567,3 +567,49 @@ def test_episode_on_a_non_default_stream():
     finally:
         TrackingEnvironment.SPATIAL_ORDER_MIN = saved
         TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved_refresh
+
+
+def test_caller_supplied_processing_orders_change_nothing():
+    """ttl_env_set_processing_order with arbitrary permutations between steps
+    (and the library's own refresh in between): a scheduling hint only."""
+    from oracle import env_oracle as orc
+    from tracktolearn_amd import _lib
+    from tracktolearn_amd.environments import TrackingEnvironment
+    saved = (TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH)
+    TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH = 1, 3
+    try:
+        D, N = 16, 9000
+        sh, mask, pk = synthetic_subject(D)
+        rng = np.random.RandomState(8)
+        vox = np.argwhere(mask)
+        seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+        env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds, n_dirs=4,
+                       max_length=20.0, reward=False)
+        ref = orc.OracleTrackingEnv(sh, mask, seeds, n_dirs=4, theta=30.0,
+                                    step_size=env.step_size, max_nb_steps=env.max_nb_steps,
+                                    mask_threshold=0.1, peaks=pk, compute_reward=False,
+                                    alignment_weighting=1.0)
+        s_hip, s_ref = env.reset(0, N), ref.reset(0, N)
+        step = 0
+        while len(ref.continue_idx):
+            n = env._n_active
+            if step % 2:
+                perm = torch.randperm(n, device='cuda').to(torch.int32)
+                _lib.check(env._lib.ttl_env_set_processing_order(
+                    env._handle, perm.data_ptr(), n, env._stream()), 'set order')
+                # wrong sizes are refused, nothing is launched for them
+                assert env._lib.ttl_env_set_processing_order(
+                    env._handle, perm.data_ptr(), n + 1, env._stream()) == -1
+            a = _scripted(rng, s_ref, 7 * 45, step, 0.15)
+            ns_hip, _, d_hip, _ = env.step(a.copy())
+            ns_ref, _, d_ref, _ = ref.step(a.copy())
+            assert np.array_equal(d_hip, d_ref)
+            assert _close(ns_hip.cpu().numpy(), ns_ref)
+            s_hip, _ = env.harvest()
+            s_ref, _ = ref.harvest()
+            assert _close(s_hip.cpu().numpy(), s_ref)
+            step += 1
+        assert step > 5
+        assert np.array_equal(env.streamlines, ref.streamlines)
+    finally:
+        TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved
