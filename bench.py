@@ -118,26 +118,30 @@ def cpu_baseline(mask_data, sh, n_sample=65536, n_steps=12):
         sh, mask_data, seeds, n_dirs=N_DIRS, theta=THETA,
         step_size=np.float32(STEP_MM), max_nb_steps=int(MAX_LENGTH / STEP_MM),
         mask_threshold=0.1, compute_reward=False, spline_eval='scipy')
-    total = 0
-    elapsed = 0.0
+    rates, spent = [], 0.0
     with single_thread:
-        state = env.reset(0, n_sample)
-        for step in range(n_steps):
-            idx = env.continue_idx
-            if len(idx) == 0:
-                break
-            a = scripted_actions(state, 7 * C, idx, 1, step, WOBBLE)
-            t0 = time.perf_counter()
-            env.step(a)
-            state, _ = env.harvest()
-            elapsed += time.perf_counter() - t0
-            total += len(idx)
-    return {'value': total / elapsed, 'unit': 'streamline-steps/s', 'cores': 1,
+        for _ in range(3):                  # median of three repetitions
+            total, elapsed = 0, 0.0
+            state = env.reset(0, n_sample)
+            for step in range(n_steps):
+                idx = env.continue_idx
+                if len(idx) == 0:
+                    break
+                a = scripted_actions(state, 7 * C, idx, 1, step, WOBBLE)
+                t0 = time.perf_counter()
+                env.step(a)
+                state, _ = env.harvest()
+                elapsed += time.perf_counter() - t0
+                total += len(idx)
+            rates.append(total / elapsed)
+            spent += elapsed
+    return {'value': float(np.median(rates)), 'unit': 'streamline-steps/s', 'cores': 1,
             'kind': 'port',
             'sample': f'oracle/env_oracle.py (numpy/scipy port of the reference '
                       f'env), {n_sample} of the {N_ACTOR} streamlines, first '
-                      f'{n_steps} steps, step()+harvest() timed, 1 thread of '
-                      f'{os.cpu_count()} host cpus, {elapsed:.1f} s'}
+                      f'{n_steps} steps, step()+harvest() timed, median of 3 '
+                      f'repetitions, 1 thread of {os.cpu_count()} host cpus, '
+                      f'{spent:.1f} s'}
 
 
 def main():
