@@ -151,3 +151,12 @@ def test_library_binds_to_torchs_hip_runtime():
                          text=True)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split()[0] == '1', out.stdout
+
+
+def test_bench_algorithmic_bytes_match_the_survey_figures():
+    """A(45, 4) = 11 986 B and A(45, 100) = 14 290 B per
+    streamline-step; the dominant kernel's share is gather + history + row."""
+    import bench
+    assert bench.algorithmic_bytes(45, 4) == (11986, 4 * 56 * 45 + 12 * 5 + 4 * 327)
+    assert bench.algorithmic_bytes(45, 100)[0] == 14290
+    assert bench.algorithmic_bytes(45, 4)[1] == 11448
