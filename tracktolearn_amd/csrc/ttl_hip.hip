@@ -259,17 +259,14 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
     if (active) {
         const int g = idx[i];
         float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
-        const float p1x = h[(L - 1) * 3 + 0];
-        const float p1y = h[(L - 1) * 3 + 1];
-        const float p1z = h[(L - 1) * 3 + 2];
-        // the point before it (curvature test), fetched together with p1: six
-        // contiguous floats, one memory round trip instead of two
-        float p0x = 0.f, p0y = 0.f, p0z = 0.f;
-        if (L >= 2) {
-            p0x = h[(L - 2) * 3 + 0];
-            p0y = h[(L - 2) * 3 + 1];
-            p0z = h[(L - 2) * 3 + 2];
-        }
+        // the two newest points come from a compact per-streamline array (32 B
+        // each, walked in ascending id order = nearly sequentially), not from
+        // the history rows (3.2 KB apart: one scattered DRAM sector per
+        // streamline, which is what bounded this kernel)
+        float4 *l2 = reinterpret_cast<float4 *>(P.last2 + 8 * (size_t)g);
+        const float4 q0 = l2[0], q1 = l2[1];
+        const float p0x = q0.x, p0y = q0.y, p0z = q0.z;     // zeros while L == 1
+        const float p1x = q1.x, p1y = q1.y, p1z = q1.z;
         const float ax = actions[(size_t)i * 3 + 0];
         const float ay = actions[(size_t)i * 3 + 1];
         const float az = actions[(size_t)i * 3 + 2];
@@ -335,6 +332,8 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
         h[L * 3 + 0] = p2x;
         h[L * 3 + 1] = p2y;
         h[L * 3 + 2] = p2z;
+        l2[0] = q1;
+        l2[1] = float4{p2x, p2y, p2z, 0.0f};
 
         const int n_pts = L + 1;
         float ux, uy, uz, wx, wy, wz;
@@ -576,6 +575,9 @@ __global__ __launch_bounds__(BLOCK) void k_reset(EnvParams P, int *idx,
     h[0] = seeds[(size_t)i * 3 + 0];
     h[1] = seeds[(size_t)i * 3 + 1];
     h[2] = seeds[(size_t)i * 3 + 2];
+    float4 *l2 = reinterpret_cast<float4 *>(P.last2 + 8 * (size_t)i);
+    l2[0] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+    l2[1] = float4{h[0], h[1], h[2], 0.0f};
     P.flags[i] = 0;
     P.lengths[i] = 1;
     P.dones[i] = 0;
@@ -741,6 +743,7 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     b += align_up(n, 256);                    // stop
     b += 6 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest, proc_rank, proc x2
     b += 2 * align_up(n * 4 * sizeof(float), 256); // head, slot_head
+    b += align_up(n * 8 * sizeof(float), 256); // last2
     b += align_up(n * sizeof(int), 256);      // slot_dest
     b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
@@ -857,6 +860,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->proc[1] = (int *)w;        w += align_up(n * sizeof(int), 256);
     P.head = (float *)w;          w += align_up(n * 4 * sizeof(float), 256);
     P.slot_head = (float *)w;     w += align_up(n * 4 * sizeof(float), 256);
+    P.last2 = (float *)w;         w += align_up(n * 8 * sizeof(float), 256);
     P.slot_dest = (int *)w;       w += align_up(n * sizeof(int), 256);
     P.counts = (int *)w;          w += 256;
     e->order_ws = w;
@@ -989,7 +993,7 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
     env->use_proc = processing_order != nullptr;
     if (processing_order == TTL_ORDER_BY_POSITION) {
         // the library's own order: rows sorted by the brick of their seed
-        const int rc = ttl_detail_refresh_order(env->P, d.idx_a, n, 1, env->order_ws,
+        const int rc = ttl_detail_refresh_order(env->P, d.idx_a, n, env->order_ws,
                                                 env->order_ws_bytes, env->proc[0], s);
         if (rc != TTL_OK) return rc;
     } else if (env->use_proc) {
@@ -1207,7 +1211,7 @@ int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream) {
     if (!env->n_exact)
         return fail(TTL_ERR_STATE, "ttl_env_refresh_processing_order: survivor count not read back yet");
     const int *idx = env->cur ? env->d.idx_b : env->d.idx_a;
-    const int rc = ttl_detail_refresh_order(env->P, idx, env->n_active, env->length, env->order_ws,
+    const int rc = ttl_detail_refresh_order(env->P, idx, env->n_active, env->order_ws,
                                             env->order_ws_bytes, env->proc[env->proc_cur],
                                             (hipStream_t)hip_stream);
     if (rc == TTL_OK) env->use_proc = 1;

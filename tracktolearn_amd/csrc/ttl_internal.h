@@ -52,6 +52,7 @@ struct EnvParams {
     // workspace
     uint8_t *stop;     // [n_max] 1 = stopped in the last step
     float *head;       // [n_max][4] newest point of every active row (row order)
+    float *last2;      // [n_max][8] per streamline id: {p[L-2], pad, p[L-1], pad}, the two newest points
     int *rank;         // [n_max] survivors before this row inside its block
     int *surv_pos;     // [n_max] position among survivors, -1 if stopped
     int *row_dest;     // [n_max] state row written for this active row
@@ -71,9 +72,9 @@ int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx
                             const int *row_dest, const int *proc, int n_rows, int L,
                             float *out, int64_t pitch, hipStream_t s);
 // ttl_order.hip: rows 0..n-1 sorted by the 8^3-voxel brick of their newest
-// point (point L-1 of streamline idx[row]) -> order_out[n]; ws = scratch of
+// point (P.last2 of streamline idx[row]) -> order_out[n]; ws = scratch of
 // ttl_detail_order_workspace_bytes(n_max) bytes
 size_t ttl_detail_order_workspace_bytes(size_t n);
-int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, int L, char *ws,
+int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, char *ws,
                              size_t ws_bytes, int *order_out, hipStream_t s);
 #endif

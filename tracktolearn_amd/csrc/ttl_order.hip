@@ -12,15 +12,14 @@
 namespace {
 constexpr int BLOCK = TTL_BLOCK;
 
-__global__ __launch_bounds__(BLOCK) void k_order_keys(const float *__restrict__ hist,
-                                                      int max_nb_steps,
+__global__ __launch_bounds__(BLOCK) void k_order_keys(const float *__restrict__ last2,
                                                       const int *__restrict__ idx, int n,
-                                                      int L, int nbx, int nby, int nbz,
+                                                      int nbx, int nby, int nbz,
                                                       unsigned *__restrict__ keys,
                                                       int *__restrict__ rows) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const float *p = hist + ((size_t)idx[i] * (size_t)(max_nb_steps + 1) + (size_t)(L - 1)) * 3;
+    const float *p = last2 + 8 * (size_t)idx[i] + 4;     // the newest point of the streamline
     const int nb[3] = {nbx, nby, nbz};
     unsigned b[3];
 #pragma unroll
@@ -45,7 +44,7 @@ size_t ttl_detail_order_workspace_bytes(size_t n) {
     return 3 * ((n * 4 + 255) / 256 * 256) + (4u << 20) + n * 24;
 }
 
-int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, int L, char *ws,
+int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, char *ws,
                              size_t ws_bytes, int *order_out, hipStream_t s) {
     const size_t slab = ((size_t)n * 4 + 255) / 256 * 256;
     if (ws_bytes < 3 * slab) return fail(TTL_ERR_INVALID, "order refresh: workspace too small");
@@ -63,8 +62,8 @@ int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, int L, c
     }
     unsigned bits = 1;
     while ((1ull << bits) < bricks) ++bits;
-    hipLaunchKernelGGL(k_order_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P.hist,
-                       P.max_nb_steps, idx, n, L, nb[0], nb[1], nb[2], keys_in, rows_in);
+    hipLaunchKernelGGL(k_order_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P.last2,
+                       idx, n, nb[0], nb[1], nb[2], keys_in, rows_in);
     HIP_TRY(hipGetLastError());
     size_t need = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, rows_in, order_out,
