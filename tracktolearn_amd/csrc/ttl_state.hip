@@ -263,6 +263,19 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
         py = h[(L - 1) * 3 + 1];
         pz = h[(L - 1) * 3 + 2];
     }
+    // this lane's first direction segment (np.diff of the stored float32
+    // positions): a scattered sector of the history, i.e. the longest latency
+    // of the wave -- fetched now, used after the gather
+    const int n_seg = L - 1;
+    float dvx = 0.0f, dvy = 0.0f, dvz = 0.0f;
+    if (sub < P.n_dirs && sub < n_seg) {
+        const float *a = h + (L - 2 - sub) * 3;   // points L-2-sub and L-1-sub
+        const float ax = a[0], ay = a[1], az = a[2];
+        const float bx = a[3], by = a[4], bz = a[5];
+        dvx = bx - ax;
+        dvy = by - ay;
+        dvz = bz - az;
+    }
     float *orow = out + (size_t)r * (size_t)pitch;
     const int C = P.n_coef;
     const int C4 = P.coef_pitch >> 2;
@@ -379,8 +392,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     // stored float32 positions): one whole segment (3 floats from 6
     // contiguous ones) per lane and iteration
     float *od = orow + 7 * C;
-    const int n_seg = L - 1;
-    for (int j = sub; j < P.n_dirs; j += LPS) {
+    if (sub < P.n_dirs) {
+        od[3 * sub + 0] = dvx;
+        od[3 * sub + 1] = dvy;
+        od[3 * sub + 2] = dvz;
+    }
+    for (int j = sub + LPS; j < P.n_dirs; j += LPS) {   // K > lane group size
         float vx = 0.0f, vy = 0.0f, vz = 0.0f;
         if (j < n_seg) {
             const float *a = h + (L - 2 - j) * 3;   // points L-2-j and L-1-j
