@@ -388,7 +388,8 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
         P.stop[i] = stop ? 1 : 0;
         // newest point, in row order: the state gather reads it without the
         // idx -> history indirection (one dependent memory round trip less)
-        *reinterpret_cast<float4 *>(P.head + 4 * (size_t)i) = float4{p2x, p2y, p2z, 0.0f};
+        *reinterpret_cast<float4 *>(P.head + 4 * (size_t)i) =
+            float4{p2x, p2y, p2z, __int_as_float(g)};
     }
 
     block_survivor_ranks(P, i, active, active && !stop);
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
     int dest = i;
     if (order == TTL_ORDER_PARTITION) dest = stop ? total + (i - pos) : pos;
     P.row_dest[i] = dest;
+    *reinterpret_cast<int2 *>(P.pos_dest + 2 * (size_t)i) = int2{stop ? -1 : pos, dest};
 }
 
 // ---------------------------------------------------------------------------
@@ -512,15 +514,17 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
     const int j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= n_active) return;
     const int row = proc[j];
-    const int pos = P.surv_pos[row];
+    const int2 pd = *reinterpret_cast<const int2 *>(P.pos_dest + 2 * (size_t)row);
+    const int pos = pd.x;
     if (pos >= 0) proc_next[before + P.proc_rank[j]] = pos;
     // everything this step's state gather needs to know about slot j, in slot
     // order: one thread per slot resolves the row indirections here, so the
     // gather (12 lanes per slot) starts from two coalesced loads
-    float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
-    hp.w = __int_as_float(idx[row]);
-    *reinterpret_cast<float4 *>(P.slot_head + 4 * (size_t)j) = hp;
-    P.slot_dest[j] = P.row_dest[row];
+    // (two scattered loads per slot: the packed {surv_pos, row_dest} above and
+    // the head record, whose .w already carries idx[row])
+    *reinterpret_cast<float4 *>(P.slot_head + 4 * (size_t)j) =
+        *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
+    P.slot_dest[j] = pd.y;
 }
 
 // stopping flags of caller-supplied tails (n_pts points per streamline)
@@ -744,6 +748,7 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     b += 6 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest, proc_rank, proc x2
     b += 2 * align_up(n * 4 * sizeof(float), 256); // head, slot_head
     b += align_up(n * 8 * sizeof(float), 256); // last2
+    b += align_up(n * 2 * sizeof(int), 256);   // pos_dest
     b += align_up(n * sizeof(int), 256);      // slot_dest
     b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
@@ -861,6 +866,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.head = (float *)w;          w += align_up(n * 4 * sizeof(float), 256);
     P.slot_head = (float *)w;     w += align_up(n * 4 * sizeof(float), 256);
     P.last2 = (float *)w;         w += align_up(n * 8 * sizeof(float), 256);
+    P.pos_dest = (int *)w;        w += align_up(n * 2 * sizeof(int), 256);
     P.slot_dest = (int *)w;       w += align_up(n * sizeof(int), 256);
     P.counts = (int *)w;          w += 256;
     e->order_ws = w;

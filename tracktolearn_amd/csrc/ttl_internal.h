@@ -51,7 +51,8 @@ struct EnvParams {
     uint8_t *dones;
     // workspace
     uint8_t *stop;     // [n_max] 1 = stopped in the last step
-    float *head;       // [n_max][4] newest point of every active row (row order)
+    float *head;       // [n_max][4] newest point of every active row (row order), .w = bits of idx[row]
+    int *pos_dest;     // [n_max][2] {surv_pos, row_dest} of every active row, packed for k_proc_scatter
     float *last2;      // [n_max][8] per streamline id: {p[L-2], pad, p[L-1], pad}, the two newest points
     int *rank;         // [n_max] survivors before this row inside its block
     int *surv_pos;     // [n_max] position among survivors, -1 if stopped
