@@ -67,12 +67,26 @@ def main():
         out[k] = dict(launches=len(f), fetch_kib=fa, write_kib=wa,
                       hbm_bytes_per_launch=hbm)
         lines.append(f'{k} | {len(f)} | {fa:.1f} | {wa:.1f} | {hbm:.4g}')
-    open(os.path.join(HERE, f'{tag}_pmc_traffic.txt'), 'w').write(
-        '\n'.join(lines) + '\n')
     state = [k for k in out if k.startswith('k_state')]
     js = {'source': f'profiles/{tag}_pmc_traffic.txt', 'kernels': out}
     if state:
-        js['k_state_hbm_bytes_per_launch'] = out[state[0]]['hbm_bytes_per_launch']
+        k = max(state, key=lambda name: out[name]['launches'])
+        js['k_state_kernel'] = k
+        js['k_state_hbm_bytes_per_launch'] = out[k]['hbm_bytes_per_launch']
+        # units (streamlines) per launch from the launch geometry the counter
+        # rows carry: a 256-thread workgroup of k_state_dd<LPS,...> serves
+        # 4 waves x (64 // LPS) streamlines
+        m = re.match(r'k_state(?:_dd)?<(\d+)', k)
+        rows_per_block = 4 * (64 // int(m.group(1))) if m else 20
+        units = sum(g // 256 * rows_per_block for _, g in fetch.get(k, []))
+        total = out[k]['hbm_bytes_per_launch'] * out[k]['launches']
+        js['k_state_units_per_launch'] = units / max(out[k]['launches'], 1)
+        js['k_state_hbm_bytes_per_unit'] = total / max(units, 1)
+        lines.append(f'{k}: {js["k_state_units_per_launch"]:.0f} units/launch (from '
+                     f'the grid sizes) -> {js["k_state_hbm_bytes_per_unit"]:.1f} HBM '
+                     f'bytes per unit')
+    open(os.path.join(HERE, f'{tag}_pmc_traffic.txt'), 'w').write(
+        '\n'.join(lines) + '\n')
     json.dump(js, open(os.path.join(HERE, 'pmc_traffic.json'), 'w'), indent=1)
     print('\n'.join(lines))
 

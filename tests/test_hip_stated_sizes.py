@@ -1,0 +1,528 @@
+"""GPU parity at the stated sizes of BASELINE.json configs 3 and 5.
+
+ * config 3 (`sac_auto_train.py`, SAC hidden 1024-1024, n_actor 65 536, 96^3,
+   K = 4, alignment reward on, batch 4 096, replay 10^6): one whole training
+   episode (`Tracker.track_and_train` -> `SACAuto._episode`: policy forward,
+   env step, replay add, sample, update every step) with the policy's actions
+   recorded; the CPU oracle replays the first steps on every row (state,
+   reward, done, replay rows) and the whole episode for flags / lengths.
+   Then `SACAuto.update` on the MI355X against the same update on the CPU
+   (same weights, same 4 096-row batch, same injected gaussian draws).
+ * config 5's per-GPU shard (16 384 streamlines, oracle bonus 10, oracle
+   batches of 4 096 rows -- OracleSingleton's tail-batch quirk is live,
+   TrackToLearn/oracles/oracle.py:62-84): oracle decisions re-derived on the
+   CPU from the downloaded streamlines.  TractOracle-Net weights and dipy's
+   resampler are absent offline -> parity of the *scores* is unpinned
+   (random weights, restated resampler); the batching, the thresholding and
+   the sparse bonus are what this pins.
+
+Tolerances: stopping masks / indices / flags bit-exact; state and reward
+1e-5; learner see `test_config3_update_on_gpu_matches_cpu`.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+DEV = 'cuda:0'
+
+
+def _env(D, N, K, *, reward, min_length, max_length, dto_extra=None, seed=3,
+         split='training'):
+    from tracktolearn_amd.environments import TrackingEnvironment
+    from tracktolearn_amd.utils.synthetic import (synthetic_seeds,
+                                                  synthetic_subject)
+    subject = synthetic_subject(D, 45, seed=1234, peaks=True,
+                                affine_dtype=np.float32)
+    dto = dict(n_dirs=K, theta=30.0, npv=1, binary_stopping_threshold=0.1,
+               step_size=0.75, min_length=min_length, max_length=max_length,
+               compute_reward=reward, alignment_weighting=1.0, oracle_bonus=0.0,
+               rng=np.random.RandomState(0), device=torch.device(DEV),
+               target_sh_order=8)
+    dto.update(dto_extra or {})
+    env = TrackingEnvironment(subject, split, dto)
+    env.seeds = synthetic_seeds(subject[1].data, N, seed=seed)
+    return env, subject
+
+
+class _Recorder:
+    """Wraps an agent's select_action and keeps every action batch."""
+
+    def __init__(self, agent):
+        self.actions = []
+        self._orig = agent.select_action
+        agent.select_action = self
+
+    def __call__(self, state, probabilistic=1.0):
+        a = self._orig(state, probabilistic=probabilistic)
+        self.actions.append(a.detach().cpu().numpy().copy())
+        return a
+
+
+# --------------------------------------------------------------------------
+# config 3
+# --------------------------------------------------------------------------
+C3 = dict(N=65536, D=96, K=4, hidden='1024-1024', batch=4096, replay=10 ** 6)
+
+
+@pytest.fixture(scope='module')
+def config3_run():
+    """One training episode at config 3's stated size; shared by the tests."""
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    from tracktolearn_amd.tracking.tracker import Tracker
+    torch.manual_seed(3)
+    np.random.seed(3)
+    N, K = C3['N'], C3['K']
+    env, subject = _env(C3['D'], N, K, reward=True, min_length=20.0,
+                        max_length=200.0)
+    W = env.get_state_size()
+    assert W == 327 and env.max_nb_steps == 266
+    alg = SACAuto(W, 3, C3['hidden'], n_actors=N, batch_size=C3['batch'],
+                  replay_size=C3['replay'], rng=None, device=torch.device(DEV))
+    assert [tuple(p.shape) for p in alg.agent.actor.parameters()][:4] == \
+        [(1024, 327), (1024,), (1024, 1024), (1024,)]
+    alg.start_timesteps = N         # one step of pure collection, then updates
+    rec = _Recorder(alg.agent)
+    tracker = Tracker(alg, n_actor=N)
+    tractogram, losses, reward, factors = tracker.track_and_train(env)
+    print(f'config-3 episode: {len(rec.actions)} steps, '
+          f'{sum(len(a) for a in rec.actions)} transitions, {alg.total_it} updates')
+    return dict(env=env, subject=subject, alg=alg, rec=rec, reward=reward,
+                tractogram=tractogram, factors=factors)
+
+
+def test_config3_training_episode_matches_oracle(config3_run):
+    from oracle import env_oracle as orc
+    r = config3_run
+    env, subject, alg, rec = r['env'], r['subject'], r['alg'], r['rec']
+    N, K = C3['N'], C3['K']
+    n_steps = len(rec.actions)
+    n_transitions = sum(len(a) for a in rec.actions)
+    assert len(r['tractogram']) == N
+    assert alg.t == 1 + n_transitions
+    assert alg.total_it == n_steps - 1            # every step but the first
+    assert len(r['factors']['peaks_reward']) == n_steps
+    # ring arithmetic at the stated replay size (10^6 slots; wraps when the
+    # episode yields more transitions than that)
+    buf = alg.replay_buffer
+    assert len(buf) == min(n_transitions, buf.max_size)
+    assert buf.ptr == n_transitions % buf.max_size
+
+    ref = orc.OracleTrackingEnv(
+        subject[0].data, subject[1].data, np.asarray(env.initial_points),
+        n_dirs=K, theta=30.0, step_size=env.step_size,
+        max_nb_steps=env.max_nb_steps, mask_threshold=0.1,
+        peaks=subject[3].data, compute_reward=True, alignment_weighting=1.0,
+        spline_eval='scipy')
+    s_ref = ref.reset(0, N)
+    # transitions of the last steps are still in the ring (the first ones were
+    # overwritten when it wrapped): slot of transition t is t mod max_size
+    first_kept = max(0, n_transitions - buf.max_size)
+    ptr, total, checked = 0, 0.0, 0
+    for step, a in enumerate(rec.actions):
+        n = len(a)
+        assert n == len(ref.continue_idx)              # same survivors, every step
+        ns_ref, r_ref, d_ref, _ = ref.step(a.copy())
+        total += float(r_ref.sum())
+        detailed = step < 3 or (ptr >= first_kept and checked < 3)
+        if ptr >= first_kept and detailed:
+            # replay rows (s, a, s', r, 1 - done) of this step's transitions
+            slots = torch.arange(ptr, ptr + n, device=DEV) % buf.max_size
+            assert np.abs(buf.state[slots].cpu().numpy() - s_ref).max() <= TOL
+            assert np.array_equal(buf.action[slots].cpu().numpy(), a)
+            assert np.abs(buf.next_state[slots].cpu().numpy() - ns_ref).max() <= TOL
+            assert np.abs(buf.reward[slots, 0].cpu().numpy() - r_ref).max() <= TOL
+            assert np.array_equal(buf.not_done[slots, 0].cpu().numpy(),
+                                  1.0 - d_ref.astype(np.float32))
+            checked += 1
+        ptr += n
+        s_ref, _ = ref.harvest()
+    assert checked >= 3
+    assert len(ref.continue_idx) == 0
+    # stopping decisions of the whole episode, bit for bit
+    assert np.array_equal(env.flags, ref.flags)
+    assert np.array_equal(env.lengths, ref.lengths)
+    L = env.length
+    assert np.array_equal(env._buf_streamlines[:N, :L].cpu().numpy(),
+                          ref.streamlines[:, :L])
+    assert abs(r['reward'] - total) <= 1e-4 * max(1.0, abs(total))
+
+
+def test_config3_first_steps_match_oracle_on_every_row():
+    """Config 3's env (65 536 streamlines, reward on): first three steps
+    against the oracle through the reference-contract step()/harvest()."""
+    from oracle import env_oracle as orc
+    from oracle.scripted_policy import scripted_actions
+    N, K = C3['N'], C3['K']
+    env, subject = _env(C3['D'], N, K, reward=True, min_length=20.0,
+                        max_length=200.0, seed=8)
+    ref = orc.OracleTrackingEnv(
+        subject[0].data, subject[1].data, env.seeds, n_dirs=K, theta=30.0,
+        step_size=env.step_size, max_nb_steps=env.max_nb_steps,
+        mask_threshold=0.1, peaks=subject[3].data, compute_reward=True,
+        alignment_weighting=1.0, spline_eval='scipy')
+    s_hip, s_ref = env.reset(0, N), ref.reset(0, N)
+    assert np.abs(s_hip.cpu().numpy() - s_ref).max() <= TOL
+    for step in range(3):
+        a = scripted_actions(s_ref, 7 * 45, ref.continue_idx, 3, step, 0.05)
+        ns_hip, r_hip, d_hip, info = env.step(a.copy())
+        ns_ref, r_ref, d_ref, info_ref = ref.step(a.copy())
+        assert np.array_equal(d_hip, d_ref)
+        assert np.abs(ns_hip.cpu().numpy() - ns_ref).max() <= TOL
+        assert np.abs(r_hip - r_ref).max() <= TOL
+        assert abs(info['reward_info']['peaks_reward'] -
+                   info_ref['reward_info']['peaks_reward']) <= TOL
+        s_hip, _ = env.harvest()
+        s_ref, _ = ref.harvest()
+        assert np.array_equal(env.continue_idx, ref.continue_idx)
+    assert np.array_equal(env.flags, ref.flags)
+
+
+def _twin_algs(alg_src, batch_size, cls):
+    """Three learners starting from alg_src's current weights with fresh
+    optimizers: float32 on the GPU, float32 on the CPU, float64 on the CPU
+    (the referee)."""
+    W = alg_src.input_size
+    hidden = C3['hidden']
+    out = []
+    for dev, dtype in ((torch.device(DEV), torch.float32),
+                       (torch.device('cpu'), torch.float32),
+                       (torch.device('cpu'), torch.float64)):
+        alg = cls(W, 3, hidden, n_actors=8, batch_size=batch_size,
+                  replay_size=8, rng=None, device=dev)
+        for dst, src in ((alg.agent.actor, alg_src.agent.actor),
+                         (alg.agent.critic, alg_src.agent.critic),
+                         (alg.target.actor, alg_src.target.actor),
+                         (alg.target.critic, alg_src.target.critic)):
+            dst.load_state_dict({k: v.detach().to(dev).clone()
+                                 for k, v in src.state_dict().items()})
+            dst.to(dtype)
+        if hasattr(alg, 'log_alpha'):
+            alg.log_alpha.data = alg_src.log_alpha.detach().to(dev, dtype).clone()
+        out.append(alg)
+    return out
+
+
+def _err(a, ref):
+    """(max |a - ref| / max |ref|, ||a - ref||_2 / ||ref||_2)."""
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    d = a - ref
+    return (float(d.abs().max() / ref.abs().max().clamp_min(1e-30)),
+            float(d.norm() / ref.norm().clamp_min(1e-30)))
+
+
+def _sync_learner(dst, src):
+    """dst <- src: weights, targets, log_alpha and the Adam states."""
+    dev = dst.device
+    for name in ('actor', 'critic'):
+        for d_net, s_net in ((getattr(dst.agent, name), getattr(src.agent, name)),
+                             (getattr(dst.target, name), getattr(src.target, name))):
+            for pd, ps in zip(d_net.parameters(), s_net.parameters()):
+                pd.data.copy_(ps.detach().to(dev, pd.dtype))
+    dst.log_alpha.data.copy_(src.log_alpha.detach().to(dev, dst.log_alpha.dtype))
+    for od, os_ in zip(dst._optimizers(), src._optimizers()):
+        # (deep copy: load_state_dict aliases tensors that need no cast)
+        od.load_state_dict(copy.deepcopy(os_.state_dict()))
+    dst.total_it = src.total_it
+
+
+def test_config3_update_on_gpu_matches_cpu(config3_run):
+    """`SACAuto.update` (sac_auto.py:139-250) at config 3's shapes (W = 327,
+    hidden 1024-1024, batch 4 096 sampled from the episode's replay ring):
+    the MI355X update against the same update on the CPU -- same weights, same
+    batch, same injected gaussian draws -- and both against a float64 run of
+    the same update as the referee.  Two updates (the second one with Adam
+    moments in place); before the second one the CPU learners are re-synced to
+    the GPU's state, so each update is compared from identical inputs.
+
+    Stated fp32 tolerance, per parameter tensor:
+      * gradients: ||g_gpu - g_f64||_2 <= 5e-3 ||g_f64||_2.  Typical tensors
+        agree to 1e-6; the bound is set by ReLU / min(Q1, Q2) decisions that
+        sit within rounding of their boundary: with 4 096 rows x 1 024 units
+        about one pre-activation per layer does, the two devices can then
+        route that row's gradient differently (the CPU's own float32 run
+        shows the same events against float64, printed next to the GPU's);
+      * parameters after the update: >= 99.8 % of the entries within 1e-5 of
+        the CPU float32 result, none further than 2 lr = 6e-4 apart (Adam
+        moves an entry by ~lr g / (|g| + 1e-8): an entry whose gradient is
+        within rounding of 0 takes a different step on the two devices);
+        targets accordingly (tau = 0.005);
+      * log_alpha within 1e-6, its gradient within 1e-5 relative."""
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    alg_src = config3_run['alg']
+    torch.manual_seed(11)
+    batch = alg_src.replay_buffer.sample(C3['batch'])
+    assert batch[0].shape == (4096, 327)
+    gpu, cpu, f64 = _twin_algs(alg_src, C3['batch'], SACAuto)
+    g = torch.Generator().manual_seed(5)
+    eps = [torch.randn(4096, 3, generator=g) for _ in range(4)]
+    for alg, dev, dt in ((gpu, DEV, torch.float32), (cpu, 'cpu', torch.float32),
+                         (f64, 'cpu', torch.float64)):
+        draws = iter([e.to(dev, dt) for e in eps])
+        alg.noise_fn = lambda like, draws=draws: next(draws)
+    batch_cpu = [b.cpu() for b in batch]
+    batch_f64 = [b.double() for b in batch_cpu]
+    lr = 3e-4
+    stats, failures = [], []
+    for u in range(2):
+        if u:
+            _sync_learner(cpu, gpu)
+            _sync_learner(f64, gpu)
+        gpu.update(batch)
+        cpu.update(batch_cpu)
+        f64.update(batch_f64)
+        for name in ('actor', 'critic'):
+            mg, mc, m64 = (getattr(a.agent, name) for a in (gpu, cpu, f64))
+            for (k, pg), (_, pc), (_, p64) in zip(mg.named_parameters(),
+                                                  mc.named_parameters(),
+                                                  m64.named_parameters()):
+                (gm, g2), (cm, c2) = _err(pg.grad, p64.grad), _err(pc.grad, p64.grad)
+                d = (pg.detach().cpu() - pc.detach()).abs()
+                within = float((d <= 1e-5).float().mean())
+                stats.append((u, name, k, gm, g2, cm, c2, float(d.max()), within))
+                if not g2 <= 5e-3:
+                    failures.append(('grad L2 vs f64', u, name, k, g2))
+                if not float(d.max()) <= 2 * lr:
+                    failures.append(('param max', u, name, k, float(d.max())))
+                if not within >= 0.998:
+                    failures.append(('param within 1e-5', u, name, k, within))
+        for name in ('actor', 'critic'):
+            mg, mc = getattr(gpu.target, name), getattr(cpu.target, name)
+            for pg, pc in zip(mg.parameters(), mc.parameters()):
+                # target <- tau * online + (1 - tau) * target, tau = 0.005
+                dmax = float((pg.detach().cpu() - pc.detach()).abs().max())
+                if not dmax <= 2 * lr * 0.005 + 1e-7:
+                    failures.append(('target', u, name, dmax))
+        da = abs(float(gpu.log_alpha.detach()) - float(cpu.log_alpha.detach()))
+        ea = _err(gpu.log_alpha.grad, f64.log_alpha.grad)[0]
+        stats.append((u, 'log_alpha', '', ea, ea, 0.0, 0.0, da, 1.0))
+        if not da <= 1e-6 or not ea <= 1e-5:
+            failures.append(('log_alpha', u, da, ea))
+    print('config-3 update, MI355X vs CPU: update, net, tensor | gradient error '
+          'vs float64: gpu max, gpu L2, cpu32 max, cpu32 L2 | '
+          'max |param_gpu - param_cpu32|, fraction within 1e-5')
+    for row in stats:
+        print('   %d %-9s %-16s %.2e %.2e %.2e %.2e  %.2e %.5f' % row)
+    assert not failures, failures
+    assert gpu.total_it == cpu.total_it == 2
+
+
+# --------------------------------------------------------------------------
+# config 5 (one GPU's shard)
+# --------------------------------------------------------------------------
+def test_config5_shard_oracle_bonus_and_stopping(tmp_path):
+    """16 384 streamlines on 96^3, reward on, oracle_bonus 10, oracle batches
+    of 4 096 (the default): the sparse bonus on the rows that just stopped and
+    the ORACLE stop bit on all active rows, re-derived on the CPU with a
+    float32 copy of the network.  min_length is shortened so that both oracle
+    paths are live while > 4 096 streamlines are still active (the tail-batch
+    quirk needs more than one batch)."""
+    from ref_resample import resample_streamlines     # CPU re-derivation
+    from tracktolearn_amd.oracles.oracle import OracleSingleton
+    from tracktolearn_amd.oracles.transformer_oracle import (
+        TransformerOracle, save_random_checkpoint)
+    N, K, BS = 16384, 4, 4096
+    ck = save_random_checkpoint(str(tmp_path / 'o.ckpt'), n_head=4, n_layers=4,
+                                seed=5)
+
+    def make_env(ckpt):
+        OracleSingleton.reset()
+        env, subject = _env(
+            96, N, K, reward=True, min_length=1.5, max_length=200.0, seed=2,
+            dto_extra=dict(oracle_bonus=10.0, oracle_checkpoint=ckpt,
+                           oracle_stopping_criterion=True, theta=60.0))
+        assert env._oracle.batch_size == BS and env._oracle.drop_tail
+        return env
+
+    def cpu_logits(model, lines):
+        pts = torch.from_numpy(np.stack(lines))
+        lengths = torch.full((len(lines),), pts.shape[1], dtype=torch.long)
+        data = resample_streamlines(pts, lengths, 128)
+        out = []
+        with torch.no_grad():
+            for lo in range(0, len(lines), 1024):
+                p = model(data[lo:lo + 1024, 1:] - data[lo:lo + 1024, :-1]).double()
+                out.append(torch.log(p / (1 - p)))
+        return torch.cat(out).numpy()
+
+    # calibrate the random network so that its scores straddle 0.5
+    env = make_env(ck)
+    assert env.min_nb_steps == 2
+    blob = torch.load(ck, map_location='cpu', weights_only=True)
+    model = TransformerOracle.load_from_checkpoint(blob)
+    state = env.reset(0, N)
+    for step in range(8):
+        env.step_device(env.scripted_actions(state, step, 4, 0.1))
+        state, _ = env.harvest()
+    idx = env.continue_idx
+    rng = np.random.RandomState(0)
+    pick = rng.choice(len(idx), 1024, replace=False)
+    hist = env._buf_streamlines[torch.from_numpy(idx[pick]).to(DEV), :env.length].cpu().numpy()
+    logits = cpu_logits(model, list(hist))
+    # a random 4-layer network barely discriminates (its logits differ by
+    # ~1e-2 between streamlines): centre them and stretch them to a standard
+    # deviation of 2, so that the scores straddle 0.5 with a margin the GPU's
+    # fp16 autocast cannot blur
+    gain = 2.0 / float(np.std(logits))
+    blob['state_dict']['head.bias'] = \
+        (blob['state_dict']['head.bias'] - float(np.median(logits))) * gain
+    blob['state_dict']['head.weight'] = blob['state_dict']['head.weight'] * gain
+    print(f'config-5 oracle calibration: logit std {np.std(logits):.3g}, gain {gain:.3g}')
+    ck2 = str(tmp_path / 'o2.ckpt')
+    torch.save(blob, ck2)
+    cpu_model = TransformerOracle.load_from_checkpoint(
+        torch.load(ck2, map_location='cpu', weights_only=True))
+
+    def cpu_scores_at(lines):
+        return 1.0 / (1.0 + np.exp(-cpu_logits(cpu_model, lines)))
+
+    env = make_env(ck2)
+    state = env.reset(0, N)
+    saw_bonus = saw_oracle_stop = saw_oracle_keep = saw_tail = False
+    for step in range(14):
+        n = env._n_active
+        idx = env.continue_idx
+        a = env.scripted_actions(state, step, seed=4, wobble=0.1)
+        nstate, reward, done, info = env.step(a)
+        L = env.length
+        flags = env.flags
+        got = (flags[idx] & 64) != 0
+        if L > 5 * env.min_nb_steps:
+            # all n active rows were scored in batches of 4 096; rows of the
+            # final partial batch keep score 0 -> they all stop (App. E.1)
+            full = (n // BS) * BS if n > BS else n
+            if full < n:
+                saw_tail = True
+                assert got[full:].all()
+            # a random sample of the evaluated rows, re-derived on the CPU
+            rows = np.sort(rng.choice(full, 512, replace=False))
+            pts = env._buf_streamlines[torch.from_numpy(idx[rows]).to(DEV), :L].cpu().numpy()
+            sc = cpu_scores_at(list(pts))
+            sure = np.abs(sc - 0.5) > 0.1
+            print(f'config-5 step {step}: n={n} full={full} sure {sure.mean():.2f} '
+                  f'oracle-stopped {got.mean():.2f}')
+            assert sure.mean() > 0.5
+            assert np.array_equal(got[rows][sure], (sc < 0.5)[sure])
+            assert done[got].all()
+            saw_oracle_stop |= bool(got[:full].any())
+            saw_oracle_keep |= bool((~done).any())
+        else:
+            assert not got.any()
+        # the sparse bonus on the rows that just stopped
+        term = env._last_oracle_term
+        if L > env.min_nb_steps and done.any():
+            drows = np.nonzero(done)[0]
+            t = term.cpu().numpy()
+            full = (len(drows) // BS) * BS if len(drows) > BS else len(drows)
+            assert (t[drows[full:]] == 0).all()          # unevaluated tail: no bonus
+            sub = drows[:full]
+            if len(sub) > 512:
+                sub = np.sort(rng.choice(sub, 512, replace=False))
+            pts = env._buf_streamlines[torch.from_numpy(idx[sub]).to(DEV), :L].cpu().numpy()
+            sc = cpu_scores_at(list(pts))
+            sure = np.abs(sc - 0.5) > 0.1
+            assert np.array_equal((t[sub] == 10.0)[sure], (sc > 0.5)[sure])
+            assert (t[~done] == 0).all() and set(np.unique(t)) <= {0.0, 10.0}
+            assert abs(info['reward_info']['oracle_reward'] - t.mean()) < 1e-12
+            saw_bonus |= bool((t == 10.0).any())
+        state, _ = env.harvest()
+        if env._n_active == 0:
+            break
+    assert saw_bonus and saw_oracle_stop and saw_oracle_keep and saw_tail
+    OracleSingleton.reset()
+
+
+# --------------------------------------------------------------------------
+# the reference's learner vectors, replayed on the MI355X
+# --------------------------------------------------------------------------
+def _load_sd(z, prefix, dev):
+    return {k[len(prefix) + 1:]: torch.from_numpy(z[k]).to(dev)
+            for k in z.files if k.startswith(prefix + '/')}
+
+
+def _check_sd(module, z, prefix, tol):
+    want = _load_sd(z, prefix, 'cpu')
+    got = {k: v.detach().cpu() for k, v in module.state_dict().items()}
+    assert set(got) == set(want)
+    worst = 0.0
+    for k in want:
+        worst = max(worst, float((got[k] - want[k]).abs().max()))
+        assert torch.allclose(got[k], want[k], rtol=tol, atol=tol), (prefix, k)
+    return worst
+
+
+def _golden_batch(z, dev):
+    return [torch.from_numpy(z[f'batch/{n}']).to(dev) for n in
+            ('state', 'action', 'next_state', 'reward', 'not_done')]
+
+
+#: fp32 tolerance of the known-answer vectors on the GPU: the same 2e-6 the
+#: CPU run (tests/test_learner_golden.py) holds; measured worst difference on
+#: an MI355X after 3-4 updates: 2.1e-7 (sac_auto), 3e-8 (td3), 1.5e-8 (sac,
+#: ddpg).
+GOLDEN_TOL = 2e-6
+
+
+@pytest.mark.parametrize('name', ['sac_auto', 'sac', 'td3', 'ddpg'])
+def test_reference_learner_vectors_on_the_gpu(name, monkeypatch):
+    """tests/golden/learner_*.npz (recorded from the reference's
+    SACAuto / SAC / TD3 / DDPG .update with injected gaussian draws) replayed
+    by the learner running on cuda:0."""
+    from helpers import load_trace
+    from tracktolearn_amd.algorithms.ddpg import DDPG
+    from tracktolearn_amd.algorithms.sac import SAC
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    from tracktolearn_amd.algorithms.td3 import TD3
+    z = load_trace('learner_' + name)
+    dev = torch.device(DEV)
+    kw = dict(lr=3e-4, gamma=0.99, n_actors=8, batch_size=64, replay_size=1000,
+              rng=None, device=dev)
+    if name == 'sac_auto':
+        alg = SACAuto(27, 3, '32-32', alpha=0.2, **kw)
+    elif name == 'sac':
+        alg = SAC(27, 3, '32-32', alpha=0.2, **kw)
+    elif name == 'td3':
+        alg = TD3(27, 3, '32-32', action_std=float(z['action_std']), **kw)
+    else:
+        alg = DDPG(27, 3, '32-32', action_std=0.35, **kw)
+    init = (_load_sd(z, 'init/actor', dev), _load_sd(z, 'init/critic', dev))
+    alg.agent.load_state_dict(init)
+    alg.target.load_state_dict(init)
+    if name in ('sac_auto', 'sac'):
+        eps = iter(torch.from_numpy(z['eps']).reshape(-1, 64, 3).to(dev))
+        alg.noise_fn = lambda like: next(eps)
+    else:
+        eps = iter(torch.from_numpy(z['eps']).to(dev))
+        monkeypatch.setattr(torch, 'randn_like', lambda t, **kw: next(eps))
+    batch = _golden_batch(z, dev)
+    worst = 0.0
+    for u in range(int(z['n_updates'])):
+        losses = alg.update(batch)
+        worst = max(worst, _check_sd(alg.agent.actor, z, f'u{u}/actor', GOLDEN_TOL))
+        worst = max(worst, _check_sd(alg.agent.critic, z, f'u{u}/critic', GOLDEN_TOL))
+        if name != 'sac':
+            worst = max(worst, _check_sd(alg.target.actor, z, f'u{u}/target_actor', GOLDEN_TOL))
+        if name != 'ddpg':
+            worst = max(worst, _check_sd(alg.target.critic, z, f'u{u}/target_critic', GOLDEN_TOL))
+        if name == 'sac_auto':
+            assert losses == {}
+            assert np.allclose(alg.log_alpha.detach().cpu().numpy(),
+                               z[f'u{u}/log_alpha'], rtol=1e-5, atol=1e-6)
+        if name == 'sac':
+            assert abs(float(losses['critic_loss']) - float(z[f'u{u}/critic_loss'])) < 1e-4
+            assert abs(float(losses['actor_loss']) - float(z[f'u{u}/actor_loss'])) < 1e-4
+    print(f'learner_{name} on {DEV}: worst |param - reference| = {worst:.3g}')
+    assert alg.total_it == int(z['n_updates'])
+    if name == 'sac_auto':
+        st = batch[0]
+        e0 = torch.from_numpy(z['eps']).reshape(-1, 64, 3)[0].to(dev)
+        with torch.no_grad():
+            det = alg.agent.select_action(st, probabilistic=0.0)
+            a, logp = alg.agent.act(st, probabilistic=1.0, eps=e0)
+        assert np.allclose(det.cpu().numpy(), z['act_det'], atol=GOLDEN_TOL)
+        assert np.allclose(a.cpu().numpy(), z['act_sto'], atol=GOLDEN_TOL)
+        assert np.allclose(logp.cpu().numpy(), z['act_sto_logp'], atol=1e-4)

@@ -160,3 +160,31 @@ def test_bench_algorithmic_bytes_match_the_survey_figures():
     assert bench.algorithmic_bytes(45, 4) == (11986, 4 * 56 * 45 + 12 * 5 + 4 * 327)
     assert bench.algorithmic_bytes(45, 100)[0] == 14290
     assert bench.algorithmic_bytes(45, 4)[1] == 11448
+
+
+def test_sharded_tracking_draws_independent_noise_per_rank():
+    """every rank of a sharded `ttl_track` run shares the seed for
+    seed generation / shuffling but must not inject the same exploration noise
+    into row i of every shard."""
+    from types import SimpleNamespace
+    import torch
+    from tracktolearn_amd.environments.noisy_tracking_env import \
+        NoisyTrackingEnvironment
+    from tracktolearn_amd.runners.ttl_track import per_rank_noise_rng
+    actions = torch.zeros((5, 3))
+    draws = []
+    for rank in (0, 1):
+        shared = np.random.RandomState(1337)
+        env = SimpleNamespace(noise=0.1, device_noise=False, rng=shared,
+                              noise_rng=per_rank_noise_rng(1337, rank),
+                              device=torch.device('cpu'))
+        draws.append(NoisyTrackingEnvironment._noise_for(env, actions).numpy())
+        # the shared stream was not consumed: seeds / shuffles stay in step
+        assert shared.randint(1 << 30) == np.random.RandomState(1337).randint(1 << 30)
+    assert draws[0].shape == (5, 3) and draws[0].dtype == np.float64
+    assert not np.allclose(draws[0], draws[1])
+    # single process: the reference's single stream (noisy_tracking_env.py:73)
+    env = SimpleNamespace(noise=0.1, device_noise=False, noise_rng=None,
+                          rng=np.random.RandomState(7), device=torch.device('cpu'))
+    one = NoisyTrackingEnvironment._noise_for(env, actions).numpy()
+    assert np.array_equal(one, np.random.RandomState(7).normal(0., 0.1, (5, 3)))

@@ -53,13 +53,34 @@ def _worker(rank, world, port, q):
         pieces = parallel.all_gather_ragged(env._buf_lengths)
         assert [p.shape[0] for p in pieces] == [3, 5]
         lengths, flags = parallel.all_gather_tract_index(env)
-        tg = parallel.all_gather_tractogram(env)
         lines, want_flags = _expected()
-        assert len(tg) == 8 and lengths.shape[0] == 8
-        assert list(tg.data_per_streamline['flags']) == want_flags
-        assert tg.data_per_streamline['seeds'].shape == (8, 3)
-        for got, want in zip(tg.streamlines, lines):
-            assert np.array_equal(got, want)
+        # the collate the Tracker uses: exact-size gather to rank 0 only
+        rows, counts = parallel.gather_ragged_to_root(env._buf_lengths)
+        assert counts == [3, 5]
+        if rank == 0:
+            assert torch.equal(rows, lengths)
+        else:
+            assert rows is None
+        empty, counts = parallel.gather_ragged_to_root(
+            env._buf_streamlines[:0] if rank == 1 else env._buf_streamlines[:2])
+        assert counts == [2, 0] and (empty is None) == (rank == 1)
+        got = parallel.gather_tract_arrays(env)
+        if rank == 0:
+            keep_all, flags_all, pts_all, moved = got
+            assert pts_all.shape[0] == int(keep_all.sum()) == sum(len(l) for l in lines)
+            assert moved == sum(len(l) for l in lines[3:]) * 12 + 5 * (8 + 4)
+        else:
+            assert got is None
+        for tg in (parallel.all_gather_tractogram(env),
+                   parallel.gather_tractogram(env)):
+            if tg is None:
+                assert rank == 1
+                continue
+            assert len(tg) == 8 and lengths.shape[0] == 8
+            assert list(tg.data_per_streamline['flags']) == want_flags
+            assert tg.data_per_streamline['seeds'].shape == (8, 3)
+            for got_line, want in zip(tg.streamlines, lines):
+                assert np.array_equal(got_line, want)
         q.put((rank, 'ok'))
     except Exception as exc:          # pragma: no cover
         q.put((rank, repr(exc)))
@@ -157,3 +178,85 @@ def test_data_parallel_learner_world2_gloo():
                       list(alg.agent.critic.parameters()) +
                       list(alg.target.critic.parameters()) + [alg.log_alpha]]).numpy()
     assert np.abs(flat - results[0]).max() < 5e-6
+
+
+class _ToyEnv:
+    """Just enough of the env's device loop for DDPG._episode: `n` rows, a
+    fixed fraction stops at every step, all stop at `max_steps`."""
+
+    def __init__(self, n, width, max_steps, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.n, self.width, self.max_steps, self.t = n, width, max_steps, 0
+
+    def reset(self):
+        self.t = 0
+        return torch.randn(self.n, self.width, generator=self.g)
+
+    def step_device(self, action):
+        n = action.shape[0]
+        self.t += 1
+        done = (torch.rand(n, generator=self.g) < 0.3).to(torch.uint8)
+        if self.t >= self.max_steps:
+            done[:] = 1
+        keep = done == 0
+        n_keep = int(keep.sum())
+        dest = torch.empty(n, dtype=torch.int32)
+        dest[keep] = torch.arange(n_keep, dtype=torch.int32)
+        dest[~keep] = torch.arange(n_keep, n, dtype=torch.int32)
+        self._state = torch.randn(n, self.width, generator=self.g)
+        self._n_keep = n_keep
+        reward = torch.rand(n, generator=self.g).double()
+        return self._state, reward, done, {'row_dest': dest}
+
+    def harvest(self):
+        return self._state[:self._n_keep], None
+
+
+def _dp_episode_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from tracktolearn_amd.algorithms.sac_auto import SACAuto
+        W, B = 27, 16
+        torch.manual_seed(200 + rank)
+        alg = SACAuto(W, 3, '32-32', n_actors=8, batch_size=B, replay_size=500,
+                      rng=None, device=torch.device('cpu'))
+        alg.enable_data_parallel()
+        # unequal shards: rank 0 tracks 12 rows for <= 3 steps and crosses
+        # start_timesteps late, rank 1 tracks 40 rows for <= 9 steps
+        alg.start_timesteps = 20
+        env = _ToyEnv(12 if rank == 0 else 40, W, 3 if rank == 0 else 9, 5 + rank)
+        lengths = []
+        for _ in range(2):                      # two episodes back to back
+            _, _, length, _ = alg._episode(env.reset(), env)
+            lengths.append(length)
+        flat = torch.cat([p.detach().reshape(-1) for p in
+                          list(alg.agent.actor.parameters()) +
+                          list(alg.agent.critic.parameters()) + [alg.log_alpha]])
+        q.put((rank, (flat.numpy(), alg.total_it, lengths)))
+    except Exception as exc:          # pragma: no cover
+        q.put((rank, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_episode_schedule_world2_gloo():
+    """`_episode` with data-parallel replicas whose shards differ in size and
+    episode length: no rank is left alone in an all-reduce, every
+    rank performs the same number of updates, the replicas stay identical."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_episode_worker, args=(r, 2, port, q))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(v, tuple) for v in results.values()), results
+    (w0, it0, len0), (w1, it1, len1) = results[0], results[1]
+    assert it0 == it1 > 0
+    assert len0 != len1                         # the shards really differed
+    assert np.array_equal(w0, w1)

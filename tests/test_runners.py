@@ -59,7 +59,9 @@ def test_ttl_track_config1_end_to_end(tmp_path):
     from tracktolearn_amd.runners import ttl_track
     from tracktolearn_amd.tractogram import streamline_length
     paths, aff = _write_inputs(tmp_path)
-    agent_dir, hp = _write_agent(tmp_path, 7 * 45 + 3 * 4)
+    # K = 100 previous directions: the shipped model's hyper-parameters
+    # (W = 615)
+    agent_dir, hp = _write_agent(tmp_path, 7 * 45 + 3 * 100, n_dirs=100)
     out = str(tmp_path / 'out.trk')
     argv = [paths['odf'], paths['seed'], paths['mask'], out, '--agent', agent_dir,
             '--hyperparameters', hp, '--n_actor', '4096', '--npv', '1',
@@ -84,7 +86,46 @@ def test_ttl_track_config1_end_to_end(tmp_path):
     assert int(fields['count']) == len(tck) == len(tg)
 
 
-def test_from_files_needs_descoteaux_basis(tmp_path):
+@pytest.mark.gpu
+def test_ttl_track_rescales_the_step_to_the_subject_voxel_size(tmp_path, monkeypatch):
+    """runners/ttl_track.py:145-178 of the reference: an agent trained at
+    another voxel size tracks with step_size * subject_voxel / training_voxel,
+    and the *second* load_subject() re-derives step / max steps / neighbourhood
+    radius from it (environments/env.py:196-212)."""
+    from tracktolearn_amd.io import streamlines as sio
+    from tracktolearn_amd.runners import ttl_track
+    from tracktolearn_amd.tracking.tracker import Tracker
+    paths, aff = _write_inputs(tmp_path, D=24)
+    agent_dir, hp = _write_agent(tmp_path, 7 * 45 + 3 * 4)
+    hyper = json.loads(open(hp).read())
+    hyper['voxel_size'] = '2.0'            # trained at 2 mm, subject is 1 mm
+    open(hp, 'w').write(json.dumps(hyper))
+    seen = {}
+    real_track = Tracker.track
+
+    def spy(self, env, fmt):
+        seen['env'] = env
+        return real_track(self, env, fmt)
+    monkeypatch.setattr(Tracker, 'track', spy)
+    out = str(tmp_path / 'out.trk')
+    ttl_track.main([paths['odf'], paths['seed'], paths['mask'], out, '--agent',
+                    agent_dir, '--hyperparameters', hp, '--n_actor', '2000',
+                    '--min_length', '2', '--max_length', '30', '--rng_seed', '3'])
+    env = seen['env']
+    assert env.step_size_mm == 0.375
+    assert float(env.step_size) == 0.375            # 1 mm voxels
+    assert env.max_nb_steps == int(30 / 0.375) == 80
+    assert env.min_nb_steps == int(2 / 0.375)
+    assert abs(float(env.add_neighborhood_vox) - 0.375) < 1e-7
+    assert env._buf_streamlines.shape[1] == 81
+    tg, _ = sio.load_trk(out)
+    assert len(tg) > 50
+    for s in tg.streamlines[:200]:
+        seg = np.linalg.norm(np.diff(s, axis=0), axis=1)
+        assert np.abs(seg - 0.375).max() < 1e-4
+
+
+def test_set_sh_order_basis_orders_and_fullness():
     from tracktolearn_amd.datasets.utils import set_sh_order_basis
     sh = np.zeros((2, 2, 2, 28), np.float32)
     sh[..., :] = np.arange(28)
@@ -96,8 +137,47 @@ def test_from_files_needs_descoteaux_basis(tmp_path):
     full = np.tile(np.arange(81, dtype=np.float32), (2, 2, 2, 1))
     even = set_sh_order_basis(full, 'descoteaux07', target_order=8)
     assert even.shape[-1] == 45 and even[0, 0, 0, 1] == 4.0   # l=2 starts at index 4
-    with pytest.raises(NotImplementedError):
-        set_sh_order_basis(sh, 'tournier07', target_order=6)
+
+
+def test_tournier07_to_descoteaux07_conversion():
+    """`--sh_basis tournier07` (TrackToLearn/datasets/utils.py:172-175, scilpy
+    convert_sh_basis): the converted coefficients describe the same spherical
+    function -- checked by evaluating both bases on the package's hemisphere
+    -- and the conversion round-trips.  scilpy / dipy are absent, the basis
+    definitions are the published ones: PARITY UNPINNED."""
+    from tracktolearn_amd.datasets.utils import (convert_sh_basis,
+                                                 set_sh_order_basis)
+    from tracktolearn_amd.reconst.peaks import hemisphere, sh_to_sf_matrix
+    verts, _ = hemisphere(3)
+    rng = np.random.RandomState(0)
+    for order in (4, 6, 8):
+        n = (order + 1) * (order + 2) // 2
+        c = rng.standard_normal((3, 2, 2, n)).astype(np.float32)
+        for legacy_in in (True, False):
+            for out_basis, legacy_out in (('descoteaux07', True),
+                                          ('descoteaux07', False),
+                                          ('tournier07', not legacy_in)):
+                d = convert_sh_basis(c, 'tournier07', out_basis, legacy_in, legacy_out)
+                assert d.dtype == np.float32 and d.shape == c.shape
+                sf_in = c @ sh_to_sf_matrix(verts, order, 'tournier07', legacy_in)
+                sf_out = d @ sh_to_sf_matrix(verts, order, out_basis, legacy_out)
+                assert np.abs(sf_in - sf_out).max() <= 1e-6 * np.abs(sf_in).max()
+                back = convert_sh_basis(d, out_basis, 'tournier07', legacy_out, legacy_in)
+                assert np.abs(back - c).max() <= 1e-6
+    # the zonal (m = 0) coefficients are common to every basis; legacy
+    # tournier07 carries no sqrt(2) on the others
+    c = np.zeros((1, 1, 1, 6), np.float32)
+    c[..., 0], c[..., 3], c[..., 1], c[..., 5] = 1.0, 2.0, 3.0, 4.0
+    d = convert_sh_basis(c, 'tournier07', 'descoteaux07')
+    assert d[0, 0, 0, 0] == 1.0 and d[0, 0, 0, 3] == 2.0
+    # (l=2, m=-2) tournier = Im Y_2^2 -> descoteaux (l=2, m=+2) = sqrt2 Im Y_2^2
+    assert np.isclose(d[0, 0, 0, 5], 3.0 / np.sqrt(2.0))
+    assert np.isclose(d[0, 0, 0, 1], 4.0 / np.sqrt(2.0))
+    # through the entry point's helper: order change + basis change
+    t = rng.standard_normal((2, 2, 2, 28)).astype(np.float32)
+    out = set_sh_order_basis(t, 'tournier07', target_order=8)
+    assert out.shape[-1] == 45 and (out[..., 28:] == 0).all()
+    assert np.allclose(out[..., :28], convert_sh_basis(t, 'tournier07'))
 
 
 def test_sac_auto_train_help():

@@ -56,6 +56,9 @@ class DDPG(RLAlgorithm):
         self.replay_buffer = OffPolicyReplayBuffer(
             input_size, action_size, max_size=replay_size, device=device)
         self.t = 1
+        #: data-parallel replicas (SAC.enable_data_parallel); see _schedule
+        self._dp = False
+        self._dp_group = None
 
     # ------------------------------------------------------------------ #
     def sample_action(self, state):
@@ -86,32 +89,39 @@ class DDPG(RLAlgorithm):
         running_losses = defaultdict(list)
         factor_means = []
         episode_length = 0
-        while state.shape[0] > 0:
-            with torch.no_grad():
-                action = self.sample_action(state)
-            n = action.shape[0]
-            next_state, reward, done, info = env.step_device(action)
-            if reward is None:
-                reward = torch.zeros(n, dtype=torch.float64, device=self.device)
-            else:
-                term = getattr(env, '_last_oracle_term', None)
-                if term is None:
-                    factor_means.append(torch.stack(
-                        [reward.mean(), torch.zeros_like(reward[0])]))
+        while True:
+            active = state.shape[0] > 0
+            keep_going, do_update = self._schedule(active, state.shape[0])
+            if not keep_going:
+                break
+            n = 0
+            if active:
+                with torch.no_grad():
+                    action = self.sample_action(state)
+                n = action.shape[0]
+                next_state, reward, done, info = env.step_device(action)
+                if reward is None:
+                    reward = torch.zeros(n, dtype=torch.float64, device=self.device)
                 else:
-                    factor_means.append(torch.stack(
-                        [(reward - term).mean(), term.mean()]))
-            # n transitions, as if n agents were gathering them (ddpg.py:194-207)
-            self.replay_buffer.add_partitioned(
-                state, action, next_state, info['row_dest'], reward, done)
-            reward_sum += reward.sum()
-            if self.t >= self.start_timesteps:
+                    term = getattr(env, '_last_oracle_term', None)
+                    if term is None:
+                        factor_means.append(torch.stack(
+                            [reward.mean(), torch.zeros_like(reward[0])]))
+                    else:
+                        factor_means.append(torch.stack(
+                            [(reward - term).mean(), term.mean()]))
+                # n transitions, as if n agents were gathering them (ddpg.py:194-207)
+                self.replay_buffer.add_partitioned(
+                    state, action, next_state, info['row_dest'], reward, done)
+                reward_sum += reward.sum()
+            if do_update:
                 batch = self.replay_buffer.sample(self.batch_size)
                 losses = self.update(batch)
                 running_losses = add_item_to_means(running_losses, losses)
             self.t += n
-            state, _ = env.harvest()
-            episode_length += 1
+            if active:
+                state, _ = env.harvest()
+                episode_length += 1
         running_reward_factors = defaultdict(list)
         if factor_means:
             means = torch.stack(factor_means).cpu().numpy()
@@ -121,6 +131,35 @@ class DDPG(RLAlgorithm):
                 running_reward_factors)
 
     # ------------------------------------------------------------------ #
+    # Data-parallel learner replicas (SAC.enable_data_parallel): `update()`
+    # then contains collectives, so every rank must call it the same number
+    # of times although shards finish their episodes at different steps and
+    # cross `start_timesteps` at different steps.  The schedule is therefore
+    # agreed per step with ONE 2-int all-reduce: the loop runs while ANY
+    # rank still tracks, and a step updates only when EVERY rank is past
+    # start_timesteps and can fill a whole batch (equal batch sizes keep the
+    # averaged gradient equal to the full-batch mean).  A rank whose shard
+    # is exhausted keeps updating from its replay ring.  Without
+    # enable_data_parallel() these are plain local tests (the reference's
+    # schedule, ddpg.py:180-219).
+    def _schedule(self, active, n_new):
+        """(keep looping, update in this step) for one iteration of
+        ``_episode``; ``n_new`` transitions are about to enter the ring."""
+        ready = self.t >= self.start_timesteps
+        if not self._dp:
+            return active, ready
+        import torch.distributed as dist
+        rows = min(len(self.replay_buffer) + n_new, self.replay_buffer.max_size)
+        ready = ready and rows >= self.batch_size
+        group = self._dp_group
+        dev = self.device if dist.get_backend(group) == 'nccl' else 'cpu'
+        # MAX over the ranks of (still tracking, not ready to update)
+        flags = torch.tensor([int(active), int(not ready)], dtype=torch.int32,
+                             device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+        any_active, any_unready = flags.tolist()
+        return bool(any_active), not any_unready
+
     def update(self, batch):
         """ddpg.py:234-319: critic regression on the noisy target action,
         then policy ascent through the critic, then Polyak averaging."""

@@ -21,11 +21,10 @@ class SAC(DDPG):
         self.noise_fn = None
         self._graph = None
         self._graph_batch = None
-        #: data-parallel learner: every rank samples its own replay ring and
-        #: the gradients are averaged over the process group before each
-        #: optimizer step (see ``enable_data_parallel``)
-        self._dp_group = None
-        self._dp = False
+        # data-parallel learner (``enable_data_parallel``): every rank samples
+        # its own replay ring and the gradients are averaged over the process
+        # group before each optimizer step; DDPG._schedule keeps the number of
+        # updates per rank equal
 
     def enable_data_parallel(self, group=None):
         """One learner replica per GPU (the reference has a single learner;

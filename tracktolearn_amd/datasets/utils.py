@@ -1,9 +1,9 @@
 """Volume container and length conversion (host side of the env path).
 
 Mirrors TrackToLearn/datasets/utils.py:10-43 (MRIDataVolume) and :88-124
-(convert_length_mm2vox).  The HDF5 / NIfTI loaders of that file depend on
-h5py / nibabel, which are absent from this image; they are "next" rows of
-SURVEY.md 8(f).
+(convert_length_mm2vox) and :127-179 (set_sh_order_basis, incl. the
+tournier07 <-> descoteaux07 conversion scilpy provides there).  The HDF5 /
+NIfTI loaders live in datasets/SubjectDataset.py and io/nifti.py.
 """
 import numpy as np
 
@@ -59,12 +59,54 @@ def _full_basis_degrees(order):
     return np.concatenate([np.full(2 * l + 1, l) for l in range(order + 1)])
 
 
+def convert_sh_basis(sh, input_basis, output_basis='descoteaux07',
+                     is_input_legacy=True, is_output_legacy=True):
+    """Re-express even-order real SH coefficients (last axis, ordered by l then
+    m = -l..l) in another real basis: tournier07 <-> descoteaux07, legacy or
+    not.  Stands in for ``scilpy.reconst.sh.convert_sh_basis`` called at
+    TrackToLearn/datasets/utils.py:172-175.
+
+    scilpy goes through the sphere (SF = SH @ B_in, then a least-squares fit
+    of the output basis); both bases span the same functions -- each real
+    basis function is a scaled Re or Im part of one complex Y_l^|m| -- so the
+    map is exactly a per-(l, |m|) swap / sign / sqrt(2) factor, applied here in
+    closed form (no sphere, no fit error).  scilpy and dipy are absent
+    offline: the basis definitions are the published ones
+    (tracktolearn_amd/reconst/peaks.py:real_sh_parts) -> PARITY UNPINNED.
+    """
+    from tracktolearn_amd.reconst.peaks import real_sh_parts
+    sh = np.asarray(sh)
+    order, full = get_sh_order_and_fullness(sh.shape[-1])
+    if full:
+        raise ValueError('convert_sh_basis needs a symmetric (even) basis')
+    p_in = real_sh_parts(input_basis, is_input_legacy)
+    p_out = real_sh_parts(output_basis, is_output_legacy)
+    src = {}
+    i = 0
+    for l in range(0, order + 1, 2):
+        for m in range(-l, l + 1):
+            part, scale = p_in(l, m)
+            src[(l, abs(m), part)] = (i, scale)
+            i += 1
+    take = np.empty(i, dtype=np.int64)
+    factor = np.empty(i, dtype=np.float64)
+    j = 0
+    for l in range(0, order + 1, 2):
+        for m in range(-l, l + 1):
+            part, scale = p_out(l, m)
+            take[j], s_in = src[(l, abs(m), part)]
+            factor[j] = s_in / scale
+            j += 1
+    return sh[..., take] * factor.astype(sh.dtype if sh.dtype.kind == 'f'
+                                         else np.float64)
+
+
 def set_sh_order_basis(sh, sh_basis, target_basis='descoteaux07', target_order=6):
-    """Bring SH coefficients to the target order (and basis).  Mirrors
+    """Bring SH coefficients to the target order and basis.  Mirrors
     TrackToLearn/datasets/utils.py:127-179: a full basis keeps only its even
-    degrees; a different order is truncated or zero padded.  Converting
-    between the tournier07 and descoteaux07 bases needs scilpy (absent): only
-    ``sh_basis == target_basis`` is accepted."""
+    degrees; a different order is truncated or zero padded; a different basis
+    is converted (``convert_sh_basis``, both bases legacy as scilpy's
+    defaults)."""
     n_coefs = sh.shape[-1]
     sh_order, full_basis = get_sh_order_and_fullness(n_coefs)
     if full_basis:
@@ -83,8 +125,7 @@ def set_sh_order_basis(sh, sh_basis, target_basis='descoteaux07', target_order=6
             n_missing = target_n_coefs - n_coefs
             sh = np.concatenate((sh, np.zeros((X, Y, Z, n_missing))), axis=-1)
     if sh_basis != target_basis:
-        raise NotImplementedError(
-            'converting SH from the {} to the {} basis needs scilpy, which is '
-            'not available here; provide {} coefficients'.format(
-                sh_basis, target_basis, target_basis))
+        print('SH coefficients are in the {} basis, converting them to {}.'
+              .format(sh_basis, target_basis))
+        sh = convert_sh_basis(sh, sh_basis, target_basis)
     return sh

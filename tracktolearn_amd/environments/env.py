@@ -132,8 +132,15 @@ class BaseEnv(object):
         else:
             # the runners call load_subject() again right after the constructor
             # (ttl_track.py:178, train.py:261): the same volumes are already
-            # packed on the device, nothing to redo
+            # packed on the device; only what derives from step_size_mm /
+            # min/max length is recomputed when the caller changed them in
+            # between (ttl_track.py:146 rescales the step to the subject's
+            # voxel size, env.py:196-212 then re-derives the step in voxels)
             if getattr(self, '_loaded_subject', None) is self.subject_data:
+                if self._tracking_params_key() != self._loaded_params_key:
+                    self._derive_tracking_params()
+                    self._destroy_handle()
+                    self._n_max = 0
                 return
             (input_volume, tracking_mask, seeding_mask, peaks,
              reference) = self.subject_data
@@ -158,19 +165,7 @@ class BaseEnv(object):
         mask_data = tracking_mask.data.astype(np.uint8)
         self.seeding_data = seeding_mask.data.astype(np.uint8)
 
-        self.step_size = convert_length_mm2vox(
-            self.step_size_mm, self.affine_vox2rasmm)
-        self.min_length = self.min_length_mm
-        self.max_length = self.max_length_mm
-        self.max_nb_steps = int(self.max_length / self.step_size_mm)
-        self.min_nb_steps = int(self.min_length / self.step_size_mm)
-        self.add_neighborhood_vox = convert_length_mm2vox(
-            self.step_size_mm, self.affine_vox2rasmm)
-        r = np.float32(self.add_neighborhood_vox)
-        eye = torch.eye(3)
-        self.neighborhood_directions = torch.cat(
-            (torch.zeros((1, 3)), eye * float(r), -eye * float(r))
-        ).to(self.device)
+        self._derive_tracking_params()
 
         self.seeds = random_seeds_from_mask(
             self.seeding_data, seeds_count=self.npv, rng=self.rng)
@@ -213,15 +208,6 @@ class BaseEnv(object):
             self._peaks_dev = torch.from_numpy(pk).to(self.device)
             self._peaks_dim = tuple(int(d) for d in pk.shape[:3])
 
-        # float32 vs float64 direction arithmetic: whatever this host's numpy
-        # gives `float32_array * step_size`
-        promoted = (np.zeros(1, np.float32) * self.step_size).dtype
-        if self._force_f64_directions:
-            self._mode = _lib.MODE_F64DIR
-        elif promoted == np.float64:
-            self._mode = _lib.MODE_F32NORM
-        else:
-            self._mode = _lib.MODE_F32
         self._curv_dot_max, self._curv_enabled = \
             curvature_dot_threshold(self.theta)
 
@@ -252,6 +238,38 @@ class BaseEnv(object):
         self._state_width = 7 * C_ + 3 * int(self.n_dirs)
 
     # ------------------------------------------------------------------ #
+    def _tracking_params_key(self):
+        return (float(self.step_size_mm), float(self.min_length_mm),
+                float(self.max_length_mm))
+
+    def _derive_tracking_params(self):
+        """env.py:196-213: step size in voxels, step counts and the
+        neighbourhood radius from step_size_mm / min / max length.  Also
+        picks the direction arithmetic (depends on the step's numpy type)."""
+        self.step_size = convert_length_mm2vox(
+            self.step_size_mm, self.affine_vox2rasmm)
+        self.min_length = self.min_length_mm
+        self.max_length = self.max_length_mm
+        self.max_nb_steps = int(self.max_length / self.step_size_mm)
+        self.min_nb_steps = int(self.min_length / self.step_size_mm)
+        self.add_neighborhood_vox = convert_length_mm2vox(
+            self.step_size_mm, self.affine_vox2rasmm)
+        r = np.float32(self.add_neighborhood_vox)
+        eye = torch.eye(3)
+        self.neighborhood_directions = torch.cat(
+            (torch.zeros((1, 3)), eye * float(r), -eye * float(r))
+        ).to(self.device)
+        # float32 vs float64 direction arithmetic: whatever this host's numpy
+        # gives `float32_array * step_size` (SURVEY F7/F8, App. D)
+        promoted = (np.zeros(1, np.float32) * self.step_size).dtype
+        if self._force_f64_directions:
+            self._mode = _lib.MODE_F64DIR
+        elif promoted == np.float64:
+            self._mode = _lib.MODE_F32NORM
+        else:
+            self._mode = _lib.MODE_F32
+        self._loaded_params_key = self._tracking_params_key()
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

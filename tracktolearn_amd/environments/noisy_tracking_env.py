@@ -29,6 +29,11 @@ class NoisyTrackingEnvironment(TrackingEnvironment):
         #: the host (not bit-compatible with the reference's RNG stream)
         self.device_noise = bool(env_dto.get('device_noise', False))
         self.max_action = 1.
+        #: generator of the exploration noise; None = ``self.rng`` (the
+        #: reference's single stream, noisy_tracking_env.py:73).  A sharded run
+        #: gives every rank its own stream (runners/ttl_track.py) so that row i
+        #: of every shard does not receive the same noise sequence.
+        self.noise_rng = env_dto.get('noise_rng')
         super().__init__(dataset_file, split_id, env_dto)
 
     def _noise_for(self, actions):
@@ -39,5 +44,6 @@ class NoisyTrackingEnvironment(TrackingEnvironment):
         if self.device_noise:
             return torch.randn(actions.shape, dtype=torch.float64,
                                device=self.device) * float(self.noise)
-        noise = self.rng.normal(0., self.noise, size=tuple(actions.shape))
+        rng = self.noise_rng if self.noise_rng is not None else self.rng
+        noise = rng.normal(0., self.noise, size=tuple(actions.shape))
         return torch.from_numpy(np.ascontiguousarray(noise)).to(self.device)

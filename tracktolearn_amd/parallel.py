@@ -5,9 +5,14 @@ The reference is single-process.  Streamlines are independent
 given the read-only volumes, so rank r of R tracks the contiguous slice
 ``shard_bounds(n, r, R)`` of every seed batch and never talks to its peers
 while stepping.  The only exchange is collating the finished tracts at
-``get_streamlines()`` time: an all-gather of (lengths, flags) followed by an
-all-gather of the ragged points padded to the longest shard -- RCCL over xGMI
-on GPUs (backend "nccl"), gloo in the CPU tests.
+``get_streamlines()`` time.  Only one rank consumes them (rank 0 writes the
+file), so the collate is a gather-to-root of exact sizes: one all-gather of
+the per-rank row counts (8 bytes each), then every rank sends its kept
+lengths / flags / seeds / packed points straight into its slice of the root's
+buffers (batched point-to-point over RCCL/xGMI -- xGMI is point to point, each
+sender uses its own link to the root; gloo in the CPU tests).  No padding, and
+1/R of the bytes an all-gather of the same data would land on every GPU.
+``all_gather_ragged`` remains for callers that need the data everywhere.
 """
 import numpy as np
 import torch
@@ -73,6 +78,82 @@ def all_gather_ragged(rows, group=None):
                       dtype=rows.dtype, device=dev)
     dist.all_gather_into_tensor(out, padded, group=group)
     return [out[r * longest:r * longest + counts[r]] for r in range(world)]
+
+
+def gather_ragged_to_root(rows, dst=0, group=None):
+    """Gather tensors whose first dimension differs per rank on rank ``dst``
+    only, exact sizes, no padding: the root allocates sum(counts) rows and
+    every other rank's send lands directly in its slice.  Returns
+    ``(all_rows, counts)`` on the root (rank order) and ``(None, counts)``
+    elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = _coll_device(group)
+    rows = rows.to(dev).contiguous()
+    counts = all_gather_counts(rows.shape[0], group)
+    ops, out = [], None
+    if rank == dst:
+        out = torch.empty((sum(counts),) + tuple(rows.shape[1:]),
+                          dtype=rows.dtype, device=dev)
+        offs = np.concatenate(([0], np.cumsum(counts)))
+        out[offs[dst]:offs[dst + 1]] = rows
+        for r in range(world):
+            if r != dst and counts[r] > 0:
+                peer = dist.get_global_rank(group, r) if group is not None else r
+                ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]],
+                                      peer, group))
+    elif rows.shape[0] > 0:
+        peer = dist.get_global_rank(group, dst) if group is not None else dst
+        ops.append(dist.P2POp(dist.isend, rows, peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out, counts
+
+
+def tract_arrays(env):
+    """This rank's finished tracts as device arrays: (kept lengths int64 (n,),
+    flags int32 (n,), packed points float32 (sum(kept), 3))."""
+    n = env._n_total
+    lengths, flags = env._buf_lengths[:n], env._buf_flags[:n]
+    keep = kept_lengths(lengths, flags)
+    return keep, flags, pack_points(env._buf_streamlines[:n], keep)
+
+
+def gather_tract_arrays(env, dst=0, group=None):
+    """Every rank's ``tract_arrays`` on rank ``dst`` (rank order): (keep,
+    flags, points, bytes received) there, None elsewhere.  This is the
+    path's one exchange step; bench.py times it as ``collate_ms``."""
+    keep, flags, points = tract_arrays(env)
+    keep_all, _ = gather_ragged_to_root(keep, dst, group)
+    flags_all, _ = gather_ragged_to_root(flags, dst, group)
+    pts_all, _ = gather_ragged_to_root(points, dst, group)
+    if keep_all is None:
+        return None
+    moved = sum(int(a.numel() - b.numel()) * a.element_size() for a, b in
+                ((keep_all, keep), (flags_all, flags), (pts_all, points)))
+    return keep_all, flags_all, pts_all, moved
+
+
+def gather_tractogram(env, dst=0, group=None):
+    """The sharded ``get_streamlines()``: every rank's finished tracts as one
+    Tractogram (rank order, then streamline order) on rank ``dst``; None on
+    the other ranks."""
+    seeds = torch.from_numpy(np.ascontiguousarray(env.initial_points,
+                                                  dtype=np.float64))
+    seeds_all, _ = gather_ragged_to_root(seeds, dst, group)
+    got = gather_tract_arrays(env, dst, group)
+    if got is None:
+        return None
+    keep_all, flags_all, pts_all, _ = got
+    keep_np = keep_all.cpu().numpy()
+    pts_np = pts_all.cpu().numpy()
+    offsets = np.concatenate(([0], np.cumsum(keep_np)))
+    lines = [pts_np[offsets[i]:offsets[i + 1]] for i in range(len(keep_np))]
+    return Tractogram(streamlines=lines,
+                      data_per_streamline={
+                          'seeds': seeds_all.cpu().numpy(),
+                          'flags': flags_all.cpu().numpy().astype(np.int64)})
 
 
 def all_gather_tract_index(env, group=None):

@@ -82,24 +82,54 @@ def hemisphere(subdivisions=3):
     return verts[upper], table
 
 
-def sh_to_sf_matrix(vertices, sh_order):
-    """(n_coef, V) matrix B with SF = SH @ B for the legacy descoteaux07 real
-    basis of even orders <= sh_order (what dipy ``sh_to_sf_matrix(sphere,
-    order, 'descoteaux07')`` returns first)."""
+def real_sh_parts(sh_basis, legacy=True):
+    """How the real basis function (l, m) of ``sh_basis`` is built from the
+    complex harmonic Y_l^|m| (Condon-Shortley phase): returns
+    ``f(l, m) -> (part, scale)`` with part 're' | 'im' | 'zonal', meaning
+    ``scale * Re/Im Y_l^|m|`` (or ``Y_l^0``).  Definitions as published in
+    dipy's ``real_sh_descoteaux_from_index`` / ``real_sh_tournier_from_index``
+    docstrings (dipy itself is absent offline -> parity unpinned):
+
+      descoteaux07 legacy      m<0: sqrt2 Re Y_l^|m|        m>0: sqrt2 Im Y_l^m
+      descoteaux07 non-legacy  m<0: sqrt2 Re Y_l^m (signed: (-1)^m sqrt2 Re Y_l^|m|)
+      tournier07 legacy        m<0: Im Y_l^|m|              m>0: Re Y_l^m   (no sqrt2)
+      tournier07 non-legacy    m<0: sqrt2 Im Y_l^|m|        m>0: sqrt2 Re Y_l^m  (MRtrix3)
+    """
+    r2 = np.sqrt(2.0)
+    if sh_basis == 'descoteaux07':
+        def parts(l, m):
+            if m == 0:
+                return 'zonal', 1.0
+            if m < 0:
+                return 're', r2 * (1.0 if legacy or m % 2 == 0 else -1.0)
+            return 'im', r2
+    elif sh_basis == 'tournier07':
+        def parts(l, m):
+            if m == 0:
+                return 'zonal', 1.0
+            scale = 1.0 if legacy else r2
+            return ('im', scale) if m < 0 else ('re', scale)
+    else:
+        raise ValueError(f'unknown SH basis {sh_basis!r}')
+    return parts
+
+
+def sh_to_sf_matrix(vertices, sh_order, sh_basis='descoteaux07', legacy=True):
+    """(n_coef, V) matrix B with SF = SH @ B for a real symmetric basis of
+    even orders <= sh_order, coefficients ordered by l then m = -l..l (what
+    dipy ``sh_to_sf_matrix(sphere, order, basis)`` returns first).  Default:
+    the legacy descoteaux07 basis the environment tracks in."""
     from scipy.special import sph_harm_y
     v = np.asarray(vertices, dtype=np.float64)
     polar = np.arccos(np.clip(v[:, 2], -1.0, 1.0))
     azim = np.arctan2(v[:, 1], v[:, 0])
+    parts = real_sh_parts(sh_basis, legacy)
     rows = []
     for l in range(0, int(sh_order) + 1, 2):
         for m in range(-l, l + 1):
             y = sph_harm_y(l, abs(m), polar, azim)
-            if m < 0:
-                rows.append(np.sqrt(2.0) * y.real)
-            elif m == 0:
-                rows.append(y.real)
-            else:
-                rows.append(np.sqrt(2.0) * y.imag)
+            part, scale = parts(l, m)
+            rows.append(scale * (y.imag if part == 'im' else y.real))
     return np.stack(rows)
 
 

@@ -9,7 +9,7 @@ Same command line as TrackToLearn/runners/ttl_track.py:
         [--binary_stopping_threshold t] [--rng_seed S]
 
 Launch with ``torchrun --nproc-per-node R`` to shard every seed batch over R
-GPUs (volumes replicated, RCCL all-gather of the finished tracts, rank 0
+GPUs (volumes replicated, RCCL gather-to-root of the finished tracts, rank 0
 writes the file).
 """
 import argparse
@@ -33,6 +33,15 @@ from tracktolearn_amd.utils.torch_utils import get_device
 _ROOT = os.sep.join(os.path.normpath(
     os.path.dirname(os.path.abspath(__file__))).split(os.sep)[:-2])
 DEFAULT_MODEL = os.path.join(_ROOT, 'models')
+
+
+def per_rank_noise_rng(rng_seed, rank):
+    """Generator of the exploration noise of one rank of a sharded run.  The
+    ranks must share ``rng_seed`` for seed generation and shuffling (every
+    rank derives the same seed list and takes its slice of each batch), so
+    the noise gets its own stream per rank; with one rank the env keeps the
+    reference's single stream."""
+    return np.random.RandomState((int(rng_seed) + 1 + int(rank)) % (2 ** 32))
 
 
 class TrackToLearnTrack(object):
@@ -131,6 +140,8 @@ class TrackToLearnTrack(object):
                           max_length=self.max_length,
                           save_seeds=self.save_seeds)
         env.load_subject()
+        if tracker.group_size > 1:
+            env.noise_rng = per_rank_noise_rng(self.random_seed, tracker.rank)
         filetype = detect_format(self.out_tractogram)
         tractogram = tracker.track(env, filetype)
         header = sio.create_tractogram_header(

@@ -38,6 +38,22 @@ def detect_format(filename):
     return None
 
 
+def to_file_space(streamline, tracts_format, affine, vox_size):
+    """Voxel space -> the space the file format expects, as the reference
+    writes it (tracker.py:127-136; pinned by tests/golden/tracker_*.npz):
+    .trk: voxmm with corner origin, ``(s + 0.5) * vox_size`` evaluated IN
+    PLACE on the float32 points (the reference edits the env's history view:
+    the sum rounds to float32, the product is taken in float64 and rounded to
+    float32); .tck: world space as ``s @ A[:3, :3] + A[:3, 3]`` in float64 --
+    a row vector times the matrix, i.e. A's transpose applied, as upstream."""
+    if tracts_format is TrkFile:
+        out = np.array(streamline, dtype=np.float32)       # a copy
+        out += 0.5
+        out *= vox_size
+        return out
+    return np.dot(streamline, affine[:3, :3]) + affine[:3, 3]
+
+
 class Tracker(object):
     """Generates streamlines with an agent, with or without training it
     (tracker.py:19-60)."""
@@ -91,10 +107,11 @@ class Tracker(object):
         with a process group, every rank's pairs, on rank 0 only."""
         points, keep_sel, seeds = self._batch_arrays(env, scaled_min, scaled_max)
         if self.group_size > 1:
-            from tracktolearn_amd.parallel import all_gather_ragged
-            points = torch.cat(all_gather_ragged(points))
-            keep_sel = torch.cat(all_gather_ragged(keep_sel))
-            seeds = torch.cat(all_gather_ragged(seeds))
+            # gather-to-root of exact sizes: only rank 0 consumes the tracts
+            from tracktolearn_amd.parallel import gather_ragged_to_root
+            points, _ = gather_ragged_to_root(points)
+            keep_sel, _ = gather_ragged_to_root(keep_sel)
+            seeds, _ = gather_ragged_to_root(seeds)
             if self.rank != 0:
                 return
         points = points.cpu().numpy()
@@ -138,11 +155,8 @@ class Tracker(object):
                     if self.compress:
                         streamline = compress_streamline(
                             streamline, compress_th_vox)
-                    if tracts_format is TrkFile:
-                        streamline = (streamline + 0.5) * vox_size
-                    else:
-                        streamline = np.dot(streamline, affine[:3, :3]) + \
-                            affine[:3, 3]
+                    streamline = to_file_space(streamline, tracts_format,
+                                               affine, vox_size)
                     seed_dict = {}
                     if self.save_seeds:
                         seed_dict = {'seeds': seed - 0.5}
