@@ -396,6 +396,17 @@ class BaseEnv(object):
         tracking_volume = MRIDataVolume(tracking.get_fdata(), tracking.affine)
         return (signal_volume, peaks_volume, tracking_volume, seeding_volume)
 
+    def set_step_size(self, step_size_mm):
+        """Change the step size (mm) of a loaded subject and re-derive what
+        depends on it (step in voxels, step counts, neighbourhood radius).
+        ``ttl_track_from_hdf5.py:134`` of the reference calls this name;
+        ``ttl_track.py:146`` assigns ``step_size_mm`` and reloads instead."""
+        self.step_size_mm = step_size_mm
+        if self._tracking_params_key() != self._loaded_params_key:
+            self._derive_tracking_params()
+            self._destroy_handle()
+            self._n_max = 0
+
     def get_state_size(self):
         """env.py:451-463."""
         example_state = self.reset(0, 1)
