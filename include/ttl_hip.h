@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TTL_ABI_VERSION 5
+#define TTL_ABI_VERSION 6
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -166,11 +166,17 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
  *   state_out [n_active][state_pitch] f32, row order per `order`
  *   reward_out[n_active] f64 or NULL  (row i = active row i, always)
  *   done_out  [n_active] u8           (row i = active row i, always)
- *   host_counts pinned host memory, 2 x int32, or NULL: receives
- *             {n_continue, n_stopped}.  The copy is issued on a side stream
- *             as soon as the stopping decisions are final -- before the state
- *             gather has run -- so that ttl_env_wait_counts() returns early
- *             and the host can queue the next step behind this one.
+ *   host_counts pinned host memory, 4 x int32, or NULL: receives
+ *             {n_continue, n_stopped, sequence, reserved}.  Large batches: a
+ *             copy issued on a side stream as soon as the stopping decisions
+ *             are final -- before the state gather has run -- so that
+ *             ttl_env_wait_counts() returns early and the host can queue the
+ *             next step behind this one.  Batches of at most 16384 rows run
+ *             prefix + compaction + gather as ONE kernel, which writes the
+ *             counts and then a process-unique sequence number straight into
+ *             this buffer (it must be device-visible pinned memory for that;
+ *             otherwise the side-stream copy is used);
+ *             ttl_env_wait_counts() polls the sequence word.
  * Normalise + scale the action, first-step flip, grow by one point, LENGTH /
  * CURVATURE / MASK stopping tests, flags and dones, alignment reward, new
  * state.  continue_idx itself only changes in ttl_env_harvest(). */

@@ -71,9 +71,17 @@ def _close(a, b, tol=TOL):
     return np.all((np.abs(a - b) <= tol) | both_nan)
 
 
+#: small batches (<= 16384 rows, no processing order) run prefix + compaction
+#: + gather as ONE kernel with a polled count word (TTL_FUSE_SMALL, default
+#: on); '0' keeps them on the three-launch path of the large batches
+FUSED = pytest.mark.parametrize('fused', ['1', '0'])
+
+
+@FUSED
 @pytest.mark.parametrize('name', TRACES)
-def test_reference_trace_step_harvest(name):
+def test_reference_trace_step_harvest(name, fused, monkeypatch):
     """step()/harvest() -- the reference's calling contract."""
+    monkeypatch.setenv('TTL_FUSE_SMALL', fused)
     z = load_trace(name)
     env = _env_from_trace(z)
     N = z['seeds'].shape[0]
@@ -113,10 +121,12 @@ def test_reference_trace_step_harvest(name):
     assert np.array_equal(tg.data_per_streamline['seeds'], z['tract_seeds'])
 
 
+@FUSED
 @pytest.mark.parametrize('name', TRACES)
-def test_reference_trace_device_loop(name):
+def test_reference_trace_device_loop(name, fused, monkeypatch):
     """step_device()/harvest(): survivors-first rows, nothing leaves the GPU
     except the 8-byte counters."""
+    monkeypatch.setenv('TTL_FUSE_SMALL', fused)
     z = load_trace(name)
     env = _env_from_trace(z)
     N = z['seeds'].shape[0]

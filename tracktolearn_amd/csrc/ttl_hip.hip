@@ -22,6 +22,8 @@
 // the gather), ttl_peaks.hip (fODF peaks), ttl_resample.hip (oracle input).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -496,12 +498,24 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
 // streamline separately.  Each step proc is compacted (stable, in proc order)
 // and renumbered with the survivors' new row ids.
 // ---------------------------------------------------------------------------
+// low 6 bits of v spread to every third bit (Morton interleave helper)
+__device__ __forceinline__ unsigned spread3(unsigned v) {
+    v &= 63u;
+    v = (v | (v << 8)) & 0x300Fu;
+    v = (v | (v << 4)) & 0x30C3u;
+    v = (v | (v << 2)) & 0x9249u;
+    return v;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
                                                         const int *__restrict__ idx,
                                                         const int *__restrict__ proc,
                                                         int *__restrict__ proc_next,
-                                                        int n_active, int n_blocks) {
+                                                        int n_active, int n_blocks,
+                                                        int local_sort) {
     __shared__ int red[BLOCK / 64];
+    __shared__ unsigned s_key[BLOCK];
+    __shared__ int s_pos[BLOCK];
     int before = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) before += P.proc_counts[b];
 #pragma unroll
@@ -512,19 +526,73 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w) before += red[w];
     const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= n_active) return;
-    const int row = proc[j];
-    const int2 pd = *reinterpret_cast<const int2 *>(P.pos_dest + 2 * (size_t)row);
-    const int pos = pd.x;
-    if (pos >= 0) proc_next[before + P.proc_rank[j]] = pos;
-    // everything this step's state gather needs to know about slot j, in slot
-    // order: one thread per slot resolves the row indirections here, so the
-    // gather (12 lanes per slot) starts from two coalesced loads
-    // (two scattered loads per slot: the packed {surv_pos, row_dest} above and
-    // the head record, whose .w already carries idx[row])
-    *reinterpret_cast<float4 *>(P.slot_head + 4 * (size_t)j) =
-        *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
-    P.slot_dest[j] = pd.y;
+    const bool active = j < n_active;
+    float4 hd = float4{0.f, 0.f, 0.f, 0.f};
+    int2 pd = int2{-1, 0};
+    if (active) {
+        const int row = proc[j];
+        pd = *reinterpret_cast<const int2 *>(P.pos_dest + 2 * (size_t)row);
+        // two scattered loads per slot: the packed {surv_pos, row_dest} above
+        // and the head record, whose .w already carries idx[row]
+        hd = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
+    }
+    if (!local_sort) {
+        if (!active) return;
+        if (pd.x >= 0) proc_next[before + P.proc_rank[j]] = pd.x;
+        // everything this step's state gather needs to know about slot j, in
+        // slot order: one thread per slot resolves the row indirections here,
+        // so the gather (12 lanes per slot) starts from two coalesced loads
+        *reinterpret_cast<float4 *>(P.slot_head + 4 * (size_t)j) = hd;
+        P.slot_dest[j] = pd.y;
+        return;
+    }
+    // Local re-sort: the 256 slots of this block are put in Morton order of
+    // the voxel their streamline sits in now.  The global order (8^3 bricks,
+    // rebuilt every few steps) decays slowly; the order INSIDE a brick decays
+    // within two steps (a step is 0.75 voxel) and decides how many of a wave's
+    // five streamlines share voxel records.  A block's slots stay the block's
+    // (the kept-slot count per block is permutation invariant), so this is a
+    // 256-key rank sort in LDS, no extra launch.
+    unsigned key = 0xFFFFFFFFu;
+    if (active) {
+        const unsigned vx = (unsigned)(int)fminf(fmaxf(floorf(hd.x), 0.0f), 1023.0f);
+        const unsigned vy = (unsigned)(int)fminf(fmaxf(floorf(hd.y), 0.0f), 1023.0f);
+        const unsigned vz = (unsigned)(int)fminf(fmaxf(floorf(hd.z), 0.0f), 1023.0f);
+        // bits above the low 6 per axis first (coarse), then the Morton code
+        const unsigned coarse = (((vx >> 6) & 3u) << 4) | (((vy >> 6) & 3u) << 2) | ((vz >> 6) & 3u);
+        const unsigned m = (spread3(vx) << 2) | (spread3(vy) << 1) | spread3(vz);
+        key = ((coarse << 18 | m) << 8) | threadIdx.x;      // unique inside the block
+    }
+    s_key[threadIdx.x] = key;
+    __syncthreads();
+    int rank = 0;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(s_key);
+#pragma unroll 8
+    for (int t = 0; t < BLOCK / 4; ++t) {
+        const uint4 q = k4[t];                 // same address in every lane: broadcast
+        rank += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
+    }
+    // sorted position `rank` of this block receives this slot's record
+    if (active) {
+        const size_t o = (size_t)blockIdx.x * BLOCK + rank;
+        *reinterpret_cast<float4 *>(P.slot_head + 4 * o) = hd;
+        P.slot_dest[o] = pd.y;
+    }
+    s_pos[rank] = active ? pd.x : -1;            // surv_pos (or -1) in sorted order
+    __syncthreads();
+    // next step's order: the survivors, in this sorted order
+    const int pos = s_pos[threadIdx.x];
+    const bool keep = pos >= 0;
+    const unsigned long long mk = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int below = __popcll(mk & ((1ull << lane) - 1ull));
+    if (lane == 0) red[wave] = __popcll(mk);
+    __syncthreads();
+    int wave_before = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w)
+        if (w < wave) wave_before += red[w];
+    if (keep) proc_next[before + wave_before + below] = pos;
 }
 
 // stopping flags of caller-supplied tails (n_pts points per streamline)
@@ -715,8 +783,15 @@ struct ttl_env {
     hipStream_t side;      // carries the early device->host copy of the counts
     hipEvent_t ev_prefix;  // main stream: k_prefix done (counts are final)
     hipEvent_t ev_counts;  // side stream: counts have landed in host memory
-    int counts_pending;    // an early copy is in flight / unread
-    const int32_t *host_counts;  // where that copy lands (caller's pinned memory)
+    int counts_pending;    // 1: an early copy is in flight / unread, 2: the step's own
+                           // kernel writes the caller's pinned buffer, host polls
+    const int32_t *host_counts;  // where the counts land (caller's pinned memory)
+    const int32_t *host_probe;   // pinned buffer whose device address is cached below
+    int *host_dev;         // device address of host_probe, null if it has none
+    int poll_seq;          // sequence number the polled word must reach
+    hipStream_t poll_stream;
+    int fuse_small;        // batches <= 16384 rows: one launch for prefix + gather
+    int local_sort;        // k_proc_scatter re-sorts each block's slots by current voxel
     int n_exact;           // n_active is the exact survivor count (read back)
     int prof_on;
     int prof_mask;    // bit k: time kernel class k
@@ -890,6 +965,14 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->ev_counts = nullptr;
     e->counts_pending = 0;
     e->host_counts = nullptr;
+    e->host_probe = nullptr;
+    e->host_dev = nullptr;
+    e->poll_seq = 0;
+    e->poll_stream = nullptr;
+    e->fuse_small = 1;
+    if (const char *v = getenv("TTL_FUSE_SMALL")) e->fuse_small = atoi(v);
+    e->local_sort = 1;
+    if (const char *v = getenv("TTL_LOCAL_SORT")) e->local_sort = atoi(v);
     e->n_exact = 0;
     e->prof_mask = 7;
     e->prof_on = 0;
@@ -1011,6 +1094,25 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
                                    state_pitch, s);
 }
 
+// side-stream copy of {n_continue, n_stopped} to the caller's pinned buffer,
+// ordered after everything queued on `s` so far
+static hipError_t ttl_copy_counts(ttl_env *env, int32_t *host_counts, hipStream_t s) {
+    hipError_t e;
+    if (!env->side) {
+        if ((e = hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&env->ev_prefix, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&env->ev_counts, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    if ((e = hipEventRecord(env->ev_prefix, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(env->side, env->ev_prefix, 0)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(host_counts, env->P.counts, 2 * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, env->side)) != hipSuccess) return e;
+    if ((e = hipEventRecord(env->ev_counts, env->side)) != hipSuccess) return e;
+    env->counts_pending = 1;
+    env->host_counts = host_counts;
+    return hipSuccess;
+}
+
 int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
                        int32_t n_active, double *reward_out, uint8_t *done_out,
                        void *hip_stream) {
@@ -1072,11 +1174,52 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
                            extra_flags, n_active, env->last_done);
         HIP_TRY(hipGetLastError());
     }
-    prof_mark(env, 1, 0, s);
     // a few thousand streamlines fit the caches in any order: stop paying for
     // the processing order in the episode's tail
     if (env->use_proc && n_active < 8192) env->use_proc = 0;
     const int *proc = env->use_proc ? env->proc[env->proc_cur] : nullptr;
+    env->stepped = 1;
+    env->last_order = order;
+    if (!proc && env->fuse_small && env->state_kernel != 0 &&
+        ttl_detail_can_fuse_tail(env->P, n_active)) {
+        // small batch: prefix + compaction + gather in ONE launch, and the
+        // survivor count written by that kernel straight into the caller's
+        // pinned buffer ({n_continue, n_stopped, sequence number}): no second
+        // launch, no side-stream copy, the host polls one word
+        int *host_word = nullptr;
+        int seq = 0;
+        if (host_counts) {
+            if (env->host_probe != host_counts) {
+                void *dev = nullptr;
+                env->host_probe = host_counts;
+                env->host_dev = nullptr;
+                if (hipHostGetDevicePointer(&dev, host_counts, 0) == hipSuccess)
+                    env->host_dev = static_cast<int *>(dev);
+                else
+                    (void)hipGetLastError();      // not pinned: copy path below
+            }
+            host_word = env->host_dev;
+            static std::atomic<int> g_seq{1};
+            seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
+            if (seq == 0) seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
+        }
+        prof_mark(env, 2, 0, s);
+        const int rc = ttl_detail_launch_fused_tail(env->P, idx, idx_next, n_active, order,
+                                                    n_pts, state_out, state_pitch,
+                                                    host_word, seq, s);
+        prof_mark(env, 2, 1, s);
+        if (rc != TTL_OK) return rc;
+        if (host_counts && host_word) {
+            env->counts_pending = 2;
+            env->host_counts = host_counts;
+            env->poll_seq = seq;
+            env->poll_stream = s;
+        } else if (host_counts) {
+            HIP_TRY(ttl_copy_counts(env, host_counts, s));
+        }
+        return TTL_OK;
+    }
+    prof_mark(env, 1, 0, s);
     hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
                        proc, n_active, nb, order, n_pts);
     prof_mark(env, 1, 1, s);
@@ -1085,27 +1228,15 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         // the survivor count is final once k_prefix has run: ship it to the
         // host on a side stream now, so the host can queue the next step
         // while k_state is still running
-        if (!env->side) {
-            HIP_TRY(hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&env->ev_prefix, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&env->ev_counts, hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(env->ev_prefix, s));
-        HIP_TRY(hipStreamWaitEvent(env->side, env->ev_prefix, 0));
-        HIP_TRY(hipMemcpyAsync(host_counts, env->P.counts, 2 * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, env->side));
-        HIP_TRY(hipEventRecord(env->ev_counts, env->side));
-        env->counts_pending = 1;
-        env->host_counts = host_counts;
+        HIP_TRY(ttl_copy_counts(env, host_counts, s));
     }
-    env->stepped = 1;
-    env->last_order = order;
     if (proc) {
         // next step's processing order: this one, compacted in its own order
         // (ranks from k_prefix) and renumbered with the survivors' new row
         // ids; plus this step's per-slot records for the gather
         hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, proc,
-                           env->proc[env->proc_cur ^ 1], n_active, nb);
+                           env->proc[env->proc_cur ^ 1], n_active, nb,
+                           env->local_sort && env->P.slot_rec);
         HIP_TRY(hipGetLastError());
     }
     prof_mark(env, 2, 0, s);
@@ -1171,7 +1302,32 @@ int ttl_env_wait_counts(ttl_env *env) {
     if (!env) return fail(TTL_ERR_INVALID, "ttl_env_wait_counts: null handle");
     if (!env->counts_pending)
         return fail(TTL_ERR_STATE, "ttl_env_wait_counts: the last step had no host_counts");
-    HIP_TRY(hipEventSynchronize(env->ev_counts));
+    if (env->counts_pending == 2) {
+        // the step's kernel writes {n_continue, n_stopped, seq} into the pinned
+        // buffer: poll the sequence word (bounded; then fall back to waiting
+        // for the stream, after which the word must be there)
+        const volatile int32_t *w = env->host_counts;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spin = 0;; ++spin) {
+            if (w[2] == env->poll_seq) {
+                seen = true;
+                break;
+            }
+            if ((spin & 1023u) == 1023u &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+                break;
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(env->poll_stream));
+            if (w[2] != env->poll_seq)
+                return fail(TTL_ERR_HIP, "ttl_env_wait_counts: the survivor count never "
+                                         "reached the pinned buffer");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        HIP_TRY(hipEventSynchronize(env->ev_counts));
+    }
     env->counts_pending = 0;
     // the handle now knows the exact number of survivors: the next step must
     // be launched for exactly that many rows

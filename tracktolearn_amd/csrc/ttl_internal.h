@@ -72,6 +72,13 @@ struct EnvParams {
 int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx,
                             const int *row_dest, const int *proc, int n_rows, int L,
                             float *out, int64_t pitch, hipStream_t s);
+// ttl_state.hip: the small-batch step tail (prefix + compaction + gather) in
+// one launch; host_word = device-visible pinned {n_continue, n_stopped, seq}
+// or null
+bool ttl_detail_can_fuse_tail(const EnvParams &P, int n_active);
+int ttl_detail_launch_fused_tail(const EnvParams &P, const int *idx, int *idx_next,
+                                 int n_active, int order, int n_pts, float *out,
+                                 int64_t pitch, int *host_word, int seq, hipStream_t s);
 // ttl_order.hip: rows 0..n-1 sorted by the 8^3-voxel brick of their newest
 // point (P.last2 of streamline idx[row]) -> order_out[n]; ws = scratch of
 // ttl_detail_order_workspace_bytes(n_max) bytes

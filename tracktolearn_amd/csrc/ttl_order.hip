@@ -5,6 +5,7 @@
 // Part of libttl_hip.so.
 #include "ttl_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -14,23 +15,29 @@ constexpr int BLOCK = TTL_BLOCK;
 
 __global__ __launch_bounds__(BLOCK) void k_order_keys(const float *__restrict__ last2,
                                                       const int *__restrict__ idx, int n,
-                                                      int nbx, int nby, int nbz,
+                                                      int nbx, int nby, int nbz, int fine,
                                                       unsigned *__restrict__ keys,
                                                       int *__restrict__ rows) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const float *p = last2 + 8 * (size_t)idx[i] + 4;     // the newest point of the streamline
     const int nb[3] = {nbx, nby, nbz};
-    unsigned b[3];
+    unsigned b[3], m = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         // brick of the voxel the point sits in; NaN and far-away points are
         // clamped into the brick grid
-        const float v = floorf((p[a] + 0.5f) * 0.125f);
+        const float vox = floorf(p[a] + 0.5f);
+        const float v = floorf(vox * 0.125f);
         b[a] = (unsigned)fminf(fmaxf(v == v ? v : 0.0f, 0.0f), (float)(nb[a] - 1));
+        // voxel inside the brick, Morton-interleaved (fine keys only)
+        const unsigned l = (unsigned)fminf(fmaxf(vox == vox ? vox - 8.0f * v : 0.0f, 0.0f), 7.0f);
+        m |= ((l & 1u) << (2 - a)) | ((l & 2u) << (4 - a)) | ((l & 4u) << (6 - a));
     }
     // dense brick index: as few significant bits (= radix passes) as possible
-    keys[i] = (b[0] * (unsigned)nby + b[1]) * (unsigned)nbz + b[2];
+    unsigned key = (b[0] * (unsigned)nby + b[1]) * (unsigned)nbz + b[2];
+    if (fine) key = (key << 9) | m;
+    keys[i] = key;
     rows[i] = i;
 }
 }  // namespace
@@ -62,8 +69,13 @@ int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, char *ws
     }
     unsigned bits = 1;
     while ((1ull << bits) < bricks) ++bits;
+    // TTL_ORDER_KEY=1: voxel-level keys (brick, then Morton code of the voxel
+    // inside the brick) -- an experiment knob, the default is the brick alone
+    int fine = 0;
+    if (const char *v = getenv("TTL_ORDER_KEY")) fine = atoi(v) != 0;
+    if (fine) bits += 9;
     hipLaunchKernelGGL(k_order_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P.last2,
-                       idx, n, nb[0], nb[1], nb[2], keys_in, rows_in);
+                       idx, n, nb[0], nb[1], nb[2], fine, keys_in, rows_in);
     HIP_TRY(hipGetLastError());
     size_t need = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, rows_in, order_out,

@@ -38,6 +38,13 @@ def random_seeds_from_mask(mask, seeds_count=1, rng=None):
     return vox + rng.uniform(size=vox.shape) - 0.5
 
 
+try:                                    # fast path: no Stream object per call
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                  # pragma: no cover
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 class BaseEnv(object):
     """Abstract tracking environment (see TrackingEnvironment)."""
 
@@ -85,6 +92,8 @@ class BaseEnv(object):
         #: interpolation it replaces could not be inspected offline
         self.sh_coord_shift = float(env_dto.get('sh_coord_shift', 0.0))
 
+        self._device_index = self.device.index if self.device.index is not None \
+            else (torch.cuda.current_device() if self.device.type == 'cuda' else 0)
         if self.device.type != 'cuda':
             raise RuntimeError(
                 'tracktolearn_amd environments run on an MI355X only '
@@ -271,7 +280,9 @@ class BaseEnv(object):
         self._loaded_params_key = self._tracking_params_key()
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        """Raw HIP stream torch currently launches on for this device (the
+        private C getter costs ~0.3 us against ~2 us for the Stream object)."""
+        return C.c_void_p(_raw_stream(self._device_index))
 
     def _destroy_handle(self):
         if getattr(self, '_handle', None):
@@ -340,7 +351,15 @@ class BaseEnv(object):
                    'ttl_env_create')
         self._handle = handle
         self._n_max = n_max
-        self._host_counts = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._buf_idx_rows = (self._buf_idx[0], self._buf_idx[1])
+        # int32 view of the library's active-row -> state-row map
+        idx_p, dest_p, length = C.c_void_p(), C.c_void_p(), C.c_int32()
+        _lib.check(self._lib.ttl_env_view(handle, C.byref(idx_p), C.byref(dest_p),
+                                          C.byref(length)), 'ttl_env_view')
+        off = dest_p.value - self._buf_ws.data_ptr()
+        self._row_dest_all = self._buf_ws[off:off + 4 * n_max].view(torch.int32)
+        self._host_counts = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._host_counts_np = self._host_counts.numpy()
 
     # ------------------------------------------------------------------ #
     @classmethod

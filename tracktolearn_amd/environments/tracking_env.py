@@ -59,7 +59,7 @@ class TrackingEnvironment(BaseEnv):
     # ------------------------------------------------------------------ #
     def _idx_view(self, n):
         """Device view (int32) of the current continue_idx."""
-        return self._buf_idx[self._cur][:n]
+        return self._buf_idx_rows[self._cur][:n]
 
     def _start(self, initial_points):
         n = int(initial_points.shape[0])
@@ -125,7 +125,9 @@ class TrackingEnvironment(BaseEnv):
     # ------------------------------------------------------------------ #
     def _actions_to_device(self, actions):
         if isinstance(actions, torch.Tensor):
-            a = actions.to(device=self.device, dtype=torch.float32)
+            a = actions
+            if a.dtype is not torch.float32 or a.device != self.device:
+                a = a.to(device=self.device, dtype=torch.float32)
         else:
             a = torch.from_numpy(
                 np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
@@ -266,16 +268,7 @@ class TrackingEnvironment(BaseEnv):
 
     def _row_dest_view(self, n):
         """int32 view of the library's active-row -> state-row map."""
-        off = getattr(self, '_row_dest_off', None)
-        if off is None or self._row_dest_handle is not self._handle:
-            from ctypes import byref, c_int32, c_void_p
-            idx_p, dest_p, length = c_void_p(), c_void_p(), c_int32()
-            _lib.check(self._lib.ttl_env_view(
-                self._handle, byref(idx_p), byref(dest_p), byref(length)),
-                'ttl_env_view')
-            off = self._row_dest_off = dest_p.value - self._buf_ws.data_ptr()
-            self._row_dest_handle = self._handle
-        return self._buf_ws[off:off + 4 * n].view(torch.int32)
+        return self._row_dest_all[:n]
 
     def harvest(self):
         """Drop the streamlines that stopped in the last step
@@ -304,7 +297,7 @@ class TrackingEnvironment(BaseEnv):
         # (side stream): this wait does not cover the state gather
         _lib.check(self._lib.ttl_env_wait_counts(self._handle),
                    'ttl_env_wait_counts')
-        n_cont = int(self._host_counts[0])
+        n_cont = int(self._host_counts_np[0])
         if order == _lib.ORDER_ACTIVE:
             new_state = out[:n_cont]
         else:
