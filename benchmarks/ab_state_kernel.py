@@ -22,8 +22,8 @@ import bench  # noqa: E402
 
 def parse(variant):
     """'k=4,r=16,fine=1,ls=1' -> dict (k: TTL_STATE_KERNEL, r: refresh period,
-    fine: TTL_ORDER_KEY, ls: TTL_LOCAL_SORT)."""
-    cfg = {'k': '4', 'r': '16', 'fine': '0', 'ls': '1'}
+    fine: TTL_ORDER_KEY, ls: TTL_LOCAL_SORT, lay: TTL_SH_LAYOUT)."""
+    cfg = {'k': '4', 'r': '16', 'fine': '2', 'ls': '1', 'lay': 'brick4', 'st': '0'}
     for part in str(variant).split(','):
         if part:
             key, val = part.split('=')
@@ -36,6 +36,8 @@ def make(variant, subject):
     os.environ['TTL_STATE_KERNEL'] = cfg['k']
     os.environ['TTL_LOCAL_SORT'] = cfg['ls']
     os.environ['TTL_ORDER_KEY'] = cfg['fine']
+    os.environ['TTL_SH_LAYOUT'] = cfg['lay']
+    os.environ['TTL_STORE_FLAVOUR'] = cfg['st']
     env = bench.make_env(subject, 'cuda:0', 0)
     env.SPATIAL_ORDER_REFRESH = int(cfg['r'])
     env._fine = cfg['fine']
@@ -57,7 +59,7 @@ def window(env, steps=12):
 
 
 def main():
-    variants = sys.argv[1:] or ['ls=0', 'ls=1', 'ls=0,fine=1', 'ls=1,fine=1', 'ls=0,fine=0', 'ls=1,fine=0']
+    variants = sys.argv[1:] or ['fine=0', 'fine=2', 'fine=3', 'fine=0,lay=linear', 'fine=2,lay=linear', 'fine=2,r=8']
     subject = bench.make_subject()
     envs = {}
     ref_states = None

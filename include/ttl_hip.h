@@ -73,13 +73,15 @@ typedef struct ttl_env_desc {
     uint32_t abi_version;  /* TTL_ABI_VERSION */
     int32_t mode;          /* TTL_MODE_*      */
 
-    /* SH volume, packed by ttl_pack_sh_volume(): [X][Y][Z][coef_pitch] f32 */
+    /* SH volume, packed by ttl_pack_sh_volume(): voxel records of coef_pitch
+     * f32, in the order sh_layout says */
     int32_t sh_dim[3];
     int32_t n_coef;        /* C (45 for SH order 8)                          */
     int32_t coef_pitch;    /* floats per voxel record, multiple of 4, >= C   */
     const float *sh_packed;
     float sh_coord_shift;  /* added to coordinates before the gather; 0.0    */
                            /* (voxel i sits at coordinate i)  */
+    int32_t sh_layout;     /* TTL_SH_LINEAR or TTL_SH_BRICK4                 */
 
     /* tracking mask: cubic B-spline coefficients, [X][Y][Z] f64
      * (scipy.ndimage.spline_filter(order=3), stopping_criteria.py:58-59)    */
@@ -124,11 +126,27 @@ typedef struct ttl_env ttl_env;
 /* Bytes of device scratch the handle needs for n_max streamlines. */
 size_t ttl_env_workspace_bytes(int32_t n_max);
 
+/* Order of the packed voxel records:
+ *   TTL_SH_LINEAR  [X][Y][Z] as the source volume;
+ *   TTL_SH_BRICK4  4x4x4-voxel bricks, each 64 consecutive records
+ *                  ([X/4][Y/4][Z/4] bricks, [4][4][4] voxels inside; dims
+ *                  rounded up to multiples of 4, padding records zero): the
+ *                  4x4x4 neighbourhood one streamline gathers then lives in
+ *                  at most 8 contiguous 64-record runs instead of 16 runs of
+ *                  4 records spread over Y*Z- and Z-record strides. */
+#define TTL_SH_LINEAR 0
+#define TTL_SH_BRICK4 1
+
+/* Number of voxel records ttl_pack_sh_volume() writes for a volume. */
+int64_t ttl_sh_volume_records(const int32_t *dim /*[3]*/, int32_t layout);
+
 /* Repack an SH volume [X][Y][Z][C] f32 (the layout of
  * TTL/environments/env.py:169-180 `data_volume`) into 16-byte aligned voxel
- * records [X][Y][Z][coef_pitch], zero padded.  Once per subject. */
-int ttl_pack_sh_volume(const float *src, float *dst, int64_t n_voxels,
-                       int32_t n_coef, int32_t coef_pitch, void *hip_stream);
+ * records of coef_pitch floats, zero padded, in `layout` order; dst holds
+ * ttl_sh_volume_records(dim, layout) records.  Once per subject. */
+int ttl_pack_sh_volume(const float *src, float *dst, const int32_t *dim /*[3]*/,
+                       int32_t n_coef, int32_t coef_pitch, int32_t layout,
+                       void *hip_stream);
 
 /* Per-cell shortcut table for the mask test (see ttl_env_desc.mask_classes):
  * 1 = all 64 spline taps of the cell are >= threshold, 2 = all are below,

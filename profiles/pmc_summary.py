@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 outputs for the judged profiles.
 
-    python profiles/pmc_summary.py <tag> <stats_dir> <fetch_dir> <write_dir>
+    python profiles/pmc_summary.py <tag> <stats_dir> <fetch_dir> <write_dir> [json_name]
 
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --kernel-trace
 --stats), profiles/<tag>_pmc_traffic.txt and profiles/pmc_traffic.json (read
@@ -48,6 +48,7 @@ def counters(dirname, counter):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    json_name = sys.argv[5] if len(sys.argv) > 5 else 'pmc_traffic.json'
     stats = glob.glob(os.path.join(stats_dir, '**', '*_kernel_stats.csv'),
                       recursive=True)[0]
     shutil.copy(stats, os.path.join(HERE, f'{tag}_kernel_stats.csv'))
@@ -87,7 +88,7 @@ def main():
                      f'bytes per unit')
     open(os.path.join(HERE, f'{tag}_pmc_traffic.txt'), 'w').write(
         '\n'.join(lines) + '\n')
-    json.dump(js, open(os.path.join(HERE, 'pmc_traffic.json'), 'w'), indent=1)
+    json.dump(js, open(os.path.join(HERE, json_name), 'w'), indent=1)
     print('\n'.join(lines))
 
 

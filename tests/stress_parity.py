@@ -35,8 +35,15 @@ def one(rng, k):
     N = int(rng.choice([1, 63, 257, 5000, 20000]))
     TrackingEnvironment.SPATIAL_ORDER_MIN = int(rng.choice([1, 1 << 30]))
     # (own generator: keeps the configurations of earlier logged runs)
-    TrackingEnvironment.SPATIAL_ORDER_REFRESH = int(
-        np.random.RandomState(1000 + k).choice([0, 1, 2, 5, 16]))
+    knobs = np.random.RandomState(1000 + k)
+    TrackingEnvironment.SPATIAL_ORDER_REFRESH = int(knobs.choice([0, 1, 2, 5, 16]))
+    # round-2 scheduling / layout knobs (none may change a result): fused small-
+    # batch tail, record order of the packed SH volume, per-block re-sort of the
+    # processing order, Morton / voxel-level order keys
+    os.environ['TTL_FUSE_SMALL'] = str(knobs.choice([0, 1]))
+    os.environ['TTL_SH_LAYOUT'] = str(knobs.choice(['brick4', 'linear']))
+    os.environ['TTL_LOCAL_SORT'] = str(knobs.choice([0, 1]))
+    os.environ['TTL_ORDER_KEY'] = str(knobs.choice([0, 1, 2, 3]))
     X, Y, Z = shape
     sh = (0.1 * rng.standard_normal((X, Y, Z, C))).astype(np.float32)
     g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing='ij'))

@@ -51,7 +51,10 @@ def test_create_rejects_bad_descriptors():
     assert b'mode' in lib.ttl_last_error()
     assert lib.ttl_env_step(None, None, None, 1, 0, None, 0, None, None, None,
                             None) == -1
-    assert lib.ttl_pack_sh_volume(None, None, 1, 1, 4, None) == -1
+    assert lib.ttl_pack_sh_volume(None, None, None, 1, 4, 0, None) == -1
+    dims = (ctypes.c_int32 * 3)(5, 6, 7)
+    assert lib.ttl_sh_volume_records(dims, 0) == 210
+    assert lib.ttl_sh_volume_records(dims, 1) == 2 * 2 * 2 * 64
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -19,6 +19,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
 ABI_VERSION = 6
+SH_LINEAR, SH_BRICK4 = 0, 1
 MODE_F32 = 0
 MODE_F64DIR = 1
 MODE_F32NORM = 2
@@ -41,6 +42,7 @@ class EnvDesc(C.Structure):
         ('coef_pitch', C.c_int32),
         ('sh_packed', C.c_void_p),
         ('sh_coord_shift', C.c_float),
+        ('sh_layout', C.c_int32),
         ('mask_dim', C.c_int32 * 3),
         ('mask_coef', C.c_void_p),
         ('mask_threshold', C.c_double),
@@ -70,8 +72,9 @@ class EnvDesc(C.Structure):
 # name -> (restype, argtypes); every symbol include/ttl_hip.h declares
 SYMBOLS = {
     'ttl_env_workspace_bytes': (C.c_size_t, [C.c_int32]),
-    'ttl_pack_sh_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
-                                      C.c_int32, C.c_int32, C.c_void_p]),
+    'ttl_sh_volume_records': (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),
+    'ttl_pack_sh_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     'ttl_mask_classes': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_double,
                                    C.c_void_p, C.c_void_p]),
     'ttl_env_create': (C.c_int, [C.POINTER(EnvDesc), C.POINTER(C.c_void_p)]),

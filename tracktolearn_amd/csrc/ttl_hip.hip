@@ -657,15 +657,22 @@ __global__ __launch_bounds__(BLOCK) void k_reset(EnvParams P, int *idx,
 }
 
 __global__ __launch_bounds__(BLOCK) void k_pack_sh(const float *__restrict__ src,
-                                                   float *__restrict__ dst,
-                                                   long long n_vox, int C,
-                                                   int pitch) {
+                                                   float *__restrict__ dst, int X, int Y,
+                                                   int Z, int C, int pitch, int brick,
+                                                   unsigned sx, unsigned sy) {
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const long long total = n_vox * pitch;
+    const long long total = (long long)X * Y * Z * pitch;
     if (t >= total) return;
     const long long v = t / pitch;
     const int c = (int)(t - v * pitch);
-    dst[t] = (c < C) ? src[v * C + c] : 0.0f;
+    const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / ((long long)Z * Y));
+    size_t rec;
+    if (brick)
+        rec = (size_t)(x >> 2) * sx + (size_t)(x & 3) * 16 + (size_t)(y >> 2) * sy +
+              (size_t)(y & 3) * 4 + (size_t)(z >> 2) * 64 + (size_t)(z & 3);
+    else
+        rec = (size_t)v;
+    dst[rec * pitch + c] = (c < C) ? src[v * C + c] : 0.0f;
 }
 
 // ---------------------------------------------------------------------------
@@ -831,20 +838,37 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     return b;
 }
 
-int ttl_pack_sh_volume(const float *src, float *dst, int64_t n_voxels,
-                       int32_t n_coef, int32_t coef_pitch, void *hip_stream) {
-    if (!src || !dst || n_voxels <= 0 || n_coef <= 0 || coef_pitch < n_coef ||
-        (coef_pitch & 3))
+int64_t ttl_sh_volume_records(const int32_t *dim, int32_t layout) {
+    if (!dim || dim[0] < 1 || dim[1] < 1 || dim[2] < 1) return 0;
+    if (layout == TTL_SH_BRICK4)
+        return (int64_t)((dim[0] + 3) / 4) * ((dim[1] + 3) / 4) * ((dim[2] + 3) / 4) * 64;
+    return (int64_t)dim[0] * dim[1] * dim[2];
+}
+
+int ttl_pack_sh_volume(const float *src, float *dst, const int32_t *dim, int32_t n_coef,
+                       int32_t coef_pitch, int32_t layout, void *hip_stream) {
+    if (!src || !dst || !dim || dim[0] < 1 || dim[1] < 1 || dim[2] < 1 || n_coef <= 0 ||
+        coef_pitch < n_coef || (coef_pitch & 3) ||
+        (layout != TTL_SH_LINEAR && layout != TTL_SH_BRICK4))
         return fail(TTL_ERR_INVALID, "ttl_pack_sh_volume: bad arguments");
     if (((uintptr_t)dst) & 15)
         return fail(TTL_ERR_INVALID, "ttl_pack_sh_volume: dst must be 16B aligned");
-    const long long total = (long long)n_voxels * coef_pitch;
+    const long long total = (long long)dim[0] * dim[1] * dim[2] * coef_pitch;
     const long long blocks = (total + BLOCK - 1) / BLOCK;
     if (blocks > 0x7fffffffLL)
         return fail(TTL_ERR_INVALID, "ttl_pack_sh_volume: volume too large");
-    hipLaunchKernelGGL(k_pack_sh, dim3((unsigned)blocks), dim3(BLOCK), 0,
-                       (hipStream_t)hip_stream, src, dst, (long long)n_voxels,
-                       n_coef, coef_pitch);
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int brick = layout == TTL_SH_BRICK4;
+    unsigned sx = 0, sy = 0;
+    if (brick) {
+        // padding records (dims rounded up to 4) are never written below
+        HIP_TRY(hipMemsetAsync(dst, 0, (size_t)ttl_sh_volume_records(dim, layout) *
+                                           coef_pitch * sizeof(float), s));
+        sy = (unsigned)((dim[2] + 3) / 4) * 64u;
+        sx = (unsigned)((dim[1] + 3) / 4) * sy;
+    }
+    hipLaunchKernelGGL(k_pack_sh, dim3((unsigned)blocks), dim3(BLOCK), 0, s, src, dst, dim[0],
+                       dim[1], dim[2], n_coef, coef_pitch, brick, sx, sy);
     HIP_TRY(hipGetLastError());
     return TTL_OK;
 }
@@ -876,6 +900,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
         if (d.compute_reward && d.peaks_dim[a] <= 0)
             return fail(TTL_ERR_INVALID, "ttl_env_create: non-positive peaks dim");
     }
+    if (d.sh_layout != TTL_SH_LINEAR && d.sh_layout != TTL_SH_BRICK4)
+        return fail(TTL_ERR_INVALID, "ttl_env_create: bad sh_layout %d", d.sh_layout);
     if (d.n_coef <= 0 || d.coef_pitch < d.n_coef || (d.coef_pitch & 3))
         return fail(TTL_ERR_INVALID, "ttl_env_create: coef_pitch must be a multiple of 4 >= n_coef");
     if (!d.sh_packed || (((uintptr_t)d.sh_packed) & 15))
@@ -909,6 +935,14 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.coef_pitch = d.coef_pitch;
     P.sh = d.sh_packed;
     P.sh_shift = d.sh_coord_shift;
+    P.sh_brick = d.sh_layout == TTL_SH_BRICK4;
+    if (P.sh_brick) {
+        P.sh_sy = (unsigned)((d.sh_dim[2] + 3) / 4) * 64u;
+        P.sh_sx = (unsigned)((d.sh_dim[1] + 3) / 4) * P.sh_sy;
+    } else {
+        P.sh_sy = (unsigned)d.sh_dim[2];
+        P.sh_sx = (unsigned)d.sh_dim[1] * (unsigned)d.sh_dim[2];
+    }
     P.mask_coef = d.mask_coef;
     P.mask_cls = d.mask_classes;
     P.mask_thr = d.mask_threshold;
@@ -960,6 +994,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.slot_rec = e->state_kernel != 2;
     P.xcd_remap = 1;
     if (const char *v = getenv("TTL_XCD_REMAP")) P.xcd_remap = atoi(v);
+    P.store_flavour = 0;
+    if (const char *v = getenv("TTL_STORE_FLAVOUR")) P.store_flavour = atoi(v);
     e->side = nullptr;
     e->ev_prefix = nullptr;
     e->ev_counts = nullptr;

@@ -30,6 +30,8 @@ struct EnvParams {
     int coef_pitch;
     const float *sh;
     float sh_shift;
+    int sh_brick;          // TTL_SH_BRICK4 record order (see ttl_hip.h)
+    unsigned sh_sx, sh_sy; // records per unit of x / y: linear Y*Z, Z; bricked: per brick step
     int mask_dim[3];
     const double *mask_coef;
     const uint8_t *mask_cls;  // per-cell class (see k_mask_classes) or null
@@ -63,9 +65,31 @@ struct EnvParams {
     float *slot_head;  // [n_max][4] per slot of the processing order: newest point, .w = bits of idx[row]
     int *slot_dest;    // [n_max] per slot of the processing order: row_dest[row]
     int slot_rec;      // the gather reads the slot records (0: resolves proc -> idx/row_dest/head itself)
+    int store_flavour; // cache policy of the state-row stores (TTL_STORE_FLAVOUR, see store16)
     int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
     int *counts;       // {n_continue, n_stopped}
 };
+
+// Record index of voxel (x, y, z) = vox_x(x) + vox_y(y) + vox_z(z), for both
+// record orders (separable, so the gather keeps per-axis partial offsets).
+__device__ __forceinline__ unsigned vox_x(const EnvParams &P, int x) {
+    return P.sh_brick ? (unsigned)(x >> 2) * P.sh_sx + (unsigned)(x & 3) * 16u
+                      : (unsigned)x * P.sh_sx;
+}
+__device__ __forceinline__ unsigned vox_y(const EnvParams &P, int y) {
+    return P.sh_brick ? (unsigned)(y >> 2) * P.sh_sy + (unsigned)(y & 3) * 4u
+                      : (unsigned)y * P.sh_sy;
+}
+__device__ __forceinline__ unsigned vox_z(const EnvParams &P, int z) {
+    return P.sh_brick ? (unsigned)(z >> 2) * 64u + (unsigned)(z & 3) : (unsigned)z;
+}
+
+// records of the packed SH volume (padding records of the bricked order included)
+inline size_t ttl_detail_sh_records(const EnvParams &P) {
+    if (!P.sh_brick) return (size_t)P.sh_dim[0] * P.sh_dim[1] * P.sh_dim[2];
+    return (size_t)((P.sh_dim[0] + 3) / 4) * ((P.sh_dim[1] + 3) / 4) *
+           ((P.sh_dim[2] + 3) / 4) * 64;
+}
 
 // ttl_state.hip: gathers the state rows of `n_rows` active rows (a step when
 // idx != nullptr, the reset otherwise) on stream s

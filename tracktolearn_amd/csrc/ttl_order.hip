@@ -1,6 +1,7 @@
 // ttl_order.hip -- processing order of the state gather rebuilt from the
 // streamlines' current positions: a key kernel (8^3-voxel brick of the newest
-// point of every active row) + a rocPRIM radix sort (12-13 key bits) of (key, row) pairs
+// point of every active row, bricks in Morton order) + a rocPRIM radix sort
+// (12-15 key bits) of (key, row) pairs
 // on workspace memory.  Scheduling only: results never depend on the order.
 // Part of libttl_hip.so.
 #include "ttl_internal.h"
@@ -34,9 +35,21 @@ __global__ __launch_bounds__(BLOCK) void k_order_keys(const float *__restrict__ 
         const unsigned l = (unsigned)fminf(fmaxf(vox == vox ? vox - 8.0f * v : 0.0f, 0.0f), 7.0f);
         m |= ((l & 1u) << (2 - a)) | ((l & 2u) << (4 - a)) | ((l & 4u) << (6 - a));
     }
-    // dense brick index: as few significant bits (= radix passes) as possible
-    unsigned key = (b[0] * (unsigned)nby + b[1]) * (unsigned)nbz + b[2];
-    if (fine) key = (key << 9) | m;
+    unsigned key;
+    if (fine & 2) {
+        // Morton code of the brick coordinates: consecutive keys are compact
+        // 3-D blobs, so the eight XCD ranges of the order are octant-like
+        // (small shared surface) instead of slabs along x
+        key = 0;
+#pragma unroll
+        for (int bit = 0; bit < 10; ++bit)
+            key |= (((b[0] >> bit) & 1u) << (3 * bit + 2)) | (((b[1] >> bit) & 1u) << (3 * bit + 1)) |
+                   (((b[2] >> bit) & 1u) << (3 * bit));
+    } else {
+        // dense brick index: as few significant bits (= radix passes) as possible
+        key = (b[0] * (unsigned)nby + b[1]) * (unsigned)nbz + b[2];
+    }
+    if (fine & 1) key = (key << 9) | m;
     keys[i] = key;
     rows[i] = i;
 }
@@ -69,11 +82,20 @@ int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, char *ws
     }
     unsigned bits = 1;
     while ((1ull << bits) < bricks) ++bits;
-    // TTL_ORDER_KEY=1: voxel-level keys (brick, then Morton code of the voxel
-    // inside the brick) -- an experiment knob, the default is the brick alone
-    int fine = 0;
-    if (const char *v = getenv("TTL_ORDER_KEY")) fine = atoi(v) != 0;
-    if (fine) bits += 9;
+    // TTL_ORDER_KEY: bit 0 = voxel-level keys (brick, then Morton code of the
+    // voxel inside the brick), bit 1 = Morton order of the bricks themselves
+    // instead of the dense x-major brick index
+    int fine = 2;
+    if (const char *v = getenv("TTL_ORDER_KEY")) fine = atoi(v) & 3;
+    if (fine & 2) {
+        int mx = nb[0] > nb[1] ? nb[0] : nb[1];
+        if (nb[2] > mx) mx = nb[2];
+        unsigned per_axis = 1;
+        while ((1 << per_axis) < mx) ++per_axis;
+        bits = 3 * per_axis;
+        if (bits > 23) return fail(TTL_ERR_INVALID, "order refresh: volume too large for Morton keys");
+    }
+    if (fine & 1) bits += 9;
     hipLaunchKernelGGL(k_order_keys, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, P.last2,
                        idx, n, nb[0], nb[1], nb[2], fine, keys_in, rows_in);
     HIP_TRY(hipGetLastError());

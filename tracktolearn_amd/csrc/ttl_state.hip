@@ -5,6 +5,13 @@
 // 4 GiB and more).  Part of libttl_hip.so.
 #include "ttl_internal.h"
 
+// The state rows are compared with the reference at 1e-5, not bit for bit (the
+// stopping decisions and positions, which are, live in ttl_hip.hip): let the
+// blends contract to FMAs here although the library is built with
+// -ffp-contract=off.  The direction block is plain float32 differences of
+// stored positions and is not affected.
+#pragma clang fp contract(fast)
+
 namespace {
 constexpr int BLOCK = TTL_BLOCK;
 
@@ -64,17 +71,18 @@ __global__ __launch_bounds__(BLOCK) void k_state(
             const int ya = min(max(iy0, 0), Y - 1), yb = min(max(iy0 + 1, 0), Y - 1);
             const int za = min(max(iz0, 0), Z - 1), zb = min(max(iz0 + 1, 0), Z - 1);
             const float ex = 1.0f - dx, ey = 1.0f - dy, ez = 1.0f - dz;
-            const size_t ra = ((size_t)xa * Y + ya) * Z, rb = ((size_t)xa * Y + yb) * Z;
-            const size_t rc = ((size_t)xb * Y + ya) * Z, rd = ((size_t)xb * Y + yb) * Z;
+            const size_t ra = (size_t)vox_x(P, xa) + vox_y(P, ya), rb = (size_t)vox_x(P, xa) + vox_y(P, yb);
+            const size_t rc = (size_t)vox_x(P, xb) + vox_y(P, ya), rd = (size_t)vox_x(P, xb) + vox_y(P, yb);
             // corner order 000,001,010,011,100,101,110,111 (x,y,z bits)
-            const float4 v0 = vol[(ra + za) * C4 + c4];
-            const float4 v1 = vol[(ra + zb) * C4 + c4];
-            const float4 v2 = vol[(rb + za) * C4 + c4];
-            const float4 v3 = vol[(rb + zb) * C4 + c4];
-            const float4 v4 = vol[(rc + za) * C4 + c4];
-            const float4 v5 = vol[(rc + zb) * C4 + c4];
-            const float4 v6 = vol[(rd + za) * C4 + c4];
-            const float4 v7 = vol[(rd + zb) * C4 + c4];
+            const size_t qa = vox_z(P, za), qb = vox_z(P, zb);
+            const float4 v0 = vol[(ra + qa) * C4 + c4];
+            const float4 v1 = vol[(ra + qb) * C4 + c4];
+            const float4 v2 = vol[(rb + qa) * C4 + c4];
+            const float4 v3 = vol[(rb + qb) * C4 + c4];
+            const float4 v4 = vol[(rc + qa) * C4 + c4];
+            const float4 v5 = vol[(rc + qb) * C4 + c4];
+            const float4 v6 = vol[(rd + qa) * C4 + c4];
+            const float4 v7 = vol[(rd + qb) * C4 + c4];
             const float w0 = (ex * ey) * ez, w1 = (ex * ey) * dz;
             const float w2 = (ex * dy) * ez, w3 = (ex * dy) * dz;
             const float w4 = (dx * ey) * ez, w5 = (dx * ey) * dz;
@@ -187,9 +195,25 @@ __device__ __forceinline__ float from_prev_lane(float v) {
 // store instructions the texture-address unit has to take), the last lane
 // writes the 16 bytes that END at the row's last coefficient, borrowing the
 // leading floats from its left neighbour; the overlap rewrites equal values.
+// 16-byte dword-aligned store of a row fragment.  flavour 0: plain (write-back,
+// the line stays in the XCD's L2); 1: sc1 (write-through, the line is dropped
+// from L2: rows are written once and never read by this kernel, so they need
+// not evict the voxel records the neighbours are about to gather); 2: nt;
+// 3: sc0 sc1.  TTL_STORE_FLAVOUR selects (measurement knob).
+__device__ __forceinline__ void store16(float *o, v4f v, int flavour) {
+    if (flavour == 0) {
+        *reinterpret_cast<v4f_dword_aligned *>(o) = v;
+    } else if (flavour == 1) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(o), "v"(v) : "memory");
+    } else if (flavour == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(o), "v"(v) : "memory");
+    } else {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(o), "v"(v) : "memory");
+    }
+}
+
 template <bool MERGE_TAIL>
-__device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
-    // (non-temporal stores were measured 33 % slower here: plain stores)
+__device__ __forceinline__ void put4(int flavour, float *o, f4 a, int c, int C) {
     if (MERGE_TAIL) {
         const f4 p{from_prev_lane(a.x), from_prev_lane(a.y), from_prev_lane(a.z),
                    from_prev_lane(a.w)};
@@ -198,11 +222,11 @@ __device__ __forceinline__ void put4(float *o, f4 a, int c, int C) {
         if (back == 1) v = v4f{p.w, a.x, a.y, a.z};
         if (back == 2) v = v4f{p.z, p.w, a.x, a.y};
         if (back == 3) v = v4f{p.y, p.z, p.w, a.x};
-        *reinterpret_cast<v4f_dword_aligned *>(o - back) = v;
+        store16(o - back, v, flavour);
         return;
     }
     if (c + 3 < C) {
-        *reinterpret_cast<v4f_dword_aligned *>(o) = v4f{a.x, a.y, a.z, a.w};
+        store16(o, v4f{a.x, a.y, a.z, a.w}, flavour);
     } else {
         if (c + 0 < C) o[0] = a.x;
         if (c + 1 < C) o[1] = a.y;
@@ -269,13 +293,12 @@ __device__ __forceinline__ void state_row_dd(const EnvParams &P, float px, float
     // byte offset of a voxel record = ox[.] + oy[.] + oz[.] (32-bit; the host
     // guarantees the volume < 4 GiB), slices f-1, f, f+1, f+2 clipped per axis
     const unsigned rec = (unsigned)C4 * 16u;
-    const unsigned sz = rec, sy = rec * (unsigned)Z, sx = sy * (unsigned)Y;
-    const unsigned x0 = clipi(ix - 1, X) * sx, x1 = clipi(ix, X) * sx,
-                   x2 = clipi(ix + 1, X) * sx, x3 = clipi(ix + 2, X) * sx;
-    const unsigned y0 = clipi(iy - 1, Y) * sy, y1 = clipi(iy, Y) * sy,
-                   y2 = clipi(iy + 1, Y) * sy, y3 = clipi(iy + 2, Y) * sy;
-    const unsigned z0 = clipi(iz - 1, Z) * sz, z1 = clipi(iz, Z) * sz,
-                   z2 = clipi(iz + 1, Z) * sz, z3 = clipi(iz + 2, Z) * sz;
+    const unsigned x0 = vox_x(P, clipi(ix - 1, X)) * rec, x1 = vox_x(P, clipi(ix, X)) * rec,
+                   x2 = vox_x(P, clipi(ix + 1, X)) * rec, x3 = vox_x(P, clipi(ix + 2, X)) * rec;
+    const unsigned y0 = vox_y(P, clipi(iy - 1, Y)) * rec, y1 = vox_y(P, clipi(iy, Y)) * rec,
+                   y2 = vox_y(P, clipi(iy + 1, Y)) * rec, y3 = vox_y(P, clipi(iy + 2, Y)) * rec;
+    const unsigned z0 = vox_z(P, clipi(iz - 1, Z)) * rec, z1 = vox_z(P, clipi(iz, Z)) * rec,
+                   z2 = vox_z(P, clipi(iz + 1, Z)) * rec, z3 = vox_z(P, clipi(iz + 2, Z)) * rec;
 #define TTL_VOX(xo, yo, zo) ((xo) + (yo) + (zo))
     // one float4 column per lane when the record fits the lane group (LOOP =
     // false, the usual case: nothing is hoisted and kept live across columns)
@@ -303,9 +326,9 @@ __device__ __forceinline__ void state_row_dd(const EnvParams &P, float px, float
                             ey, dy, ez, dz);
             const f4 b1 = blend4(v000, v001, v010, v011, ey, dy, ez, dz);
             const f4 b2 = blend4(v100, v101, v110, v111, ey, dy, ez, dz);
-            put4<MERGE_TAIL>(orow + 0 * C + c, lerp4(b1, b2, dx), c, C);
-            put4<MERGE_TAIL>(orow + 1 * C + c, lerp4(sel4(xup, b2, b1), sel4(xup, b3, b2), dxp), c, C);
-            put4<MERGE_TAIL>(orow + 4 * C + c, lerp4(sel4(xdn, b0, b1), sel4(xdn, b1, b2), dxm), c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, lerp4(b1, b2, dx), c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, lerp4(sel4(xup, b2, b1), sel4(xup, b3, b2), dxp), c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, lerp4(sel4(xdn, b0, b1), sel4(xdn, b1, b2), dxm), c, C);
         }
         // --- y axis: slices blended over (x, z) ---
         {
@@ -320,8 +343,8 @@ __device__ __forceinline__ void state_row_dd(const EnvParams &P, float px, float
                             ex, dx, ez, dz);
             const f4 b1 = blend4(v000, v001, v100, v101, ex, dx, ez, dz);
             const f4 b2 = blend4(v010, v011, v110, v111, ex, dx, ez, dz);
-            put4<MERGE_TAIL>(orow + 2 * C + c, lerp4(sel4(yup, b2, b1), sel4(yup, b3, b2), dyp), c, C);
-            put4<MERGE_TAIL>(orow + 5 * C + c, lerp4(sel4(ydn, b0, b1), sel4(ydn, b1, b2), dym), c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, lerp4(sel4(yup, b2, b1), sel4(yup, b3, b2), dyp), c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, lerp4(sel4(ydn, b0, b1), sel4(ydn, b1, b2), dym), c, C);
         }
         // --- z axis: slices blended over (x, y) ---
         {
@@ -336,8 +359,8 @@ __device__ __forceinline__ void state_row_dd(const EnvParams &P, float px, float
                             ex, dx, ey, dy);
             const f4 b1 = blend4(v000, v010, v100, v110, ex, dx, ey, dy);
             const f4 b2 = blend4(v001, v011, v101, v111, ex, dx, ey, dy);
-            put4<MERGE_TAIL>(orow + 3 * C + c, lerp4(sel4(zup, b2, b1), sel4(zup, b3, b2), dzp), c, C);
-            put4<MERGE_TAIL>(orow + 6 * C + c, lerp4(sel4(zdn, b0, b1), sel4(zdn, b1, b2), dzm), c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, lerp4(sel4(zup, b2, b1), sel4(zup, b3, b2), dzp), c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, lerp4(sel4(zdn, b0, b1), sel4(zdn, b1, b2), dzm), c, C);
         }
         if (!LOOP) break;
     }
@@ -618,14 +641,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd2(
     const int iy = (int)fminf(fmaxf(fy, -4.0f), (float)Y + 4.0f);
     const int iz = (int)fminf(fmaxf(fz, -4.0f), (float)Z + 4.0f);
     const unsigned rec = (unsigned)C4 * 16u;
-    const unsigned sz = rec, sy = rec * (unsigned)Z, sx = sy * (unsigned)Y;
     const unsigned cb = (unsigned)sub * 16u;       // this lane's column
-    const unsigned x0 = clipi(ix - 1, X) * sx + cb, x1 = clipi(ix, X) * sx + cb,
-                   x2 = clipi(ix + 1, X) * sx + cb, x3 = clipi(ix + 2, X) * sx + cb;
-    const unsigned y0 = clipi(iy - 1, Y) * sy, y1 = clipi(iy, Y) * sy,
-                   y2 = clipi(iy + 1, Y) * sy, y3 = clipi(iy + 2, Y) * sy;
-    const unsigned z0 = clipi(iz - 1, Z) * sz, z1 = clipi(iz, Z) * sz,
-                   z2 = clipi(iz + 1, Z) * sz, z3 = clipi(iz + 2, Z) * sz;
+    const unsigned x0 = vox_x(P, clipi(ix - 1, X)) * rec + cb, x1 = vox_x(P, clipi(ix, X)) * rec + cb,
+                   x2 = vox_x(P, clipi(ix + 1, X)) * rec + cb, x3 = vox_x(P, clipi(ix + 2, X)) * rec + cb;
+    const unsigned y0 = vox_y(P, clipi(iy - 1, Y)) * rec, y1 = vox_y(P, clipi(iy, Y)) * rec,
+                   y2 = vox_y(P, clipi(iy + 1, Y)) * rec, y3 = vox_y(P, clipi(iy + 2, Y)) * rec;
+    const unsigned z0 = vox_z(P, clipi(iz - 1, Z)) * rec, z1 = vox_z(P, clipi(iz, Z)) * rec,
+                   z2 = vox_z(P, clipi(iz + 1, Z)) * rec, z3 = vox_z(P, clipi(iz + 2, Z)) * rec;
     const bool col = sub < C4;          // lanes beyond the record fetch nothing
     const int c = sub * 4;
 #define TTL_VOX(xo, yo, zo) ((xo) + (yo) + (zo))
@@ -716,13 +738,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd2(
         TTL_ZPOINTS
         TTL_UNPARK_X
         if (col) {
-            put4<MERGE_TAIL>(orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(orow + 6 * C + c, o6, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
         }
     } else if (SCHED == 1) {
         TTL_YARMS
@@ -734,13 +756,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd2(
         TTL_ZPOINTS
         TTL_UNPARK_X
         if (col) {
-            put4<MERGE_TAIL>(orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(orow + 6 * C + c, o6, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
         }
     } else if (SCHED == 3) {
         // three fetch groups of at most 16 / 8 / 8 records, one axis each
@@ -762,13 +784,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd2(
             o5 = park[4][threadIdx.x];
         }
         if (col) {
-            put4<MERGE_TAIL>(orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(orow + 6 * C + c, o6, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
         }
     } else {
         TTL_YARMS
@@ -777,13 +799,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd2(
         TTL_YPOINTS
         TTL_ZPOINTS
         if (col) {
-            put4<MERGE_TAIL>(orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(orow + 6 * C + c, o6, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
+            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
         }
     }
 #undef TTL_VOX
@@ -855,8 +877,7 @@ static void launch_dd2(int state_kernel, dim3 grid, hipStream_t s, const EnvPara
 // at most 64 advance blocks.
 bool ttl_detail_can_fuse_tail(const EnvParams &P, int n_active) {
     const int C4 = P.coef_pitch >> 2;
-    const size_t vol_bytes = (size_t)P.sh_dim[0] * P.sh_dim[1] * P.sh_dim[2] *
-                             P.coef_pitch * sizeof(float);
+    const size_t vol_bytes = ttl_detail_sh_records(P) * P.coef_pitch * sizeof(float);
     return n_active <= 64 * BLOCK && P.radius > 0.0f && P.radius < 1.0f &&
            vol_bytes < (1ull << 32) && C4 <= 16 && P.n_coef >= 4;
 }
@@ -889,8 +910,7 @@ int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx
     const int C4 = P.coef_pitch >> 2;
     // the register-deduplicated kernel needs the shifted points to stay
     // within one cell of the centre: 0 < radius < 1 voxel
-    const size_t vol_bytes = (size_t)P.sh_dim[0] * P.sh_dim[1] *
-                             P.sh_dim[2] * P.coef_pitch * sizeof(float);
+    const size_t vol_bytes = ttl_detail_sh_records(P) * P.coef_pitch * sizeof(float);
     const bool dedupe = state_kernel != 0 && P.radius > 0.0f &&
                         P.radius < 1.0f && vol_bytes < (1ull << 32);
 #define TTL_LAUNCH_STATE(LPS)                                                 \

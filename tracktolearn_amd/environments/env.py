@@ -182,15 +182,20 @@ class BaseEnv(object):
         # --- device-side volumes ------------------------------------- #
         C_ = sh.shape[-1]
         pitch = (C_ + 3) // 4 * 4
-        n_vox = int(np.prod(sh.shape[:3]))
-        self._sh_packed = torch.empty((n_vox, pitch), dtype=torch.float32,
+        self._sh_dim = tuple(int(d) for d in sh.shape[:3])
+        # record order of the packed volume: 4x4x4-voxel bricks keep a
+        # streamline's neighbourhood in a few contiguous runs (ttl_hip.h)
+        self._sh_layout = _lib.SH_BRICK4 \
+            if os.environ.get('TTL_SH_LAYOUT', 'brick4') == 'brick4' else _lib.SH_LINEAR
+        dims = (C.c_int32 * 3)(*self._sh_dim)
+        n_rec = int(self._lib.ttl_sh_volume_records(dims, self._sh_layout))
+        self._sh_packed = torch.empty((n_rec, pitch), dtype=torch.float32,
                                       device=self.device)
         stream = self._stream()
         _lib.check(self._lib.ttl_pack_sh_volume(
-            self.data_volume.data_ptr(), self._sh_packed.data_ptr(), n_vox,
-            C_, pitch, stream), 'ttl_pack_sh_volume')
+            self.data_volume.data_ptr(), self._sh_packed.data_ptr(), dims,
+            C_, pitch, self._sh_layout, stream), 'ttl_pack_sh_volume')
         self._n_coef, self._coef_pitch = C_, pitch
-        self._sh_dim = tuple(int(d) for d in sh.shape[:3])
 
         # cubic B-spline coefficients: scipy on the host at load time, as
         # BinaryStoppingCriterion.__init__ does (stopping_criteria.py:58-59)
@@ -322,6 +327,7 @@ class BaseEnv(object):
         d.coef_pitch = self._coef_pitch
         d.sh_packed = self._sh_packed.data_ptr()
         d.sh_coord_shift = self.sh_coord_shift
+        d.sh_layout = self._sh_layout
         d.mask_dim[:] = self._mask_dim
         d.mask_coef = self._mask_coef.data_ptr()
         d.mask_threshold = float(self.binary_stopping_threshold)
