@@ -23,7 +23,7 @@ import bench  # noqa: E402
 def parse(variant):
     """'k=4,r=16,fine=1,ls=1' -> dict (k: TTL_STATE_KERNEL, r: refresh period,
     fine: TTL_ORDER_KEY, ls: TTL_LOCAL_SORT, lay: TTL_SH_LAYOUT)."""
-    cfg = {'k': '4', 'r': '16', 'fine': '2', 'ls': '1', 'lay': 'brick4', 'st': '0'}
+    cfg = {'k': '4', 'r': '16', 'fine': '0', 'ls': '1', 'lay': 'brick4', 'st': '0', 'd': '96'}
     for part in str(variant).split(','):
         if part:
             key, val = part.split('=')
@@ -31,8 +31,18 @@ def parse(variant):
     return cfg
 
 
+_SUBJECTS = {}
+
+
 def make(variant, subject):
     cfg = parse(variant)
+    d = int(cfg['d'])
+    if d != 96:          # another volume size (cache-residency experiments)
+        if d not in _SUBJECTS:
+            bench.D = d
+            _SUBJECTS[d] = bench.make_subject()
+            bench.D = 96
+        subject = _SUBJECTS[d]
     os.environ['TTL_STATE_KERNEL'] = cfg['k']
     os.environ['TTL_LOCAL_SORT'] = cfg['ls']
     os.environ['TTL_ORDER_KEY'] = cfg['fine']
@@ -59,44 +69,48 @@ def window(env, steps=12):
 
 
 def main():
-    variants = sys.argv[1:] or ['fine=0', 'fine=2', 'fine=3', 'fine=0,lay=linear', 'fine=2,lay=linear', 'fine=2,r=8']
+    variants = sys.argv[1:] or ['lay=brick4', 'lay=linear']
+    copies = int(os.environ.get('AB_COPIES', '2'))     # env instances per variant
     subject = bench.make_subject()
     envs = {}
-    ref_states = None
+    ref_states = {}
     for v in variants:
-        env, state = make(v, subject)
-        # correctness: first 3 steps' rows against variant 4
-        rows = [state.clone()]
-        for step in range(3):
-            a = env.scripted_actions(state, step, 1, bench.WOBBLE)
-            ns, _, _, info = env.step_device(a)
-            full = torch.empty_like(ns)
-            full[:] = ns
-            rows.append(full[info['row_dest'].long()].clone())
-            state, _ = env.harvest()
-        if ref_states is None:
-            ref_states = rows
-            diff = 0.0
-        else:
-            diff = max(float((a - b).abs().max()) for a, b in zip(rows, ref_states))
-        envs[v] = (env, diff)
-        for _ in range(2):
-            window(env)
+        envs[v] = []
+        for c in range(copies):
+            env, state = make(v, subject)
+            # correctness: first 3 steps' rows against the first variant of the
+            # same volume size
+            rows = [state.clone()]
+            for step in range(3):
+                a = env.scripted_actions(state, step, 1, bench.WOBBLE)
+                ns, _, _, info = env.step_device(a)
+                rows.append(ns[info['row_dest'].long()].clone())
+                state, _ = env.harvest()
+            d = parse(v)['d']
+            if d not in ref_states:
+                ref_states[d] = rows
+                diff = 0.0
+            else:
+                diff = max(float((a - b).abs().max()) for a, b in zip(rows, ref_states[d]))
+            envs[v].append((env, diff))
+            for _ in range(2):
+                window(env)
     results = {v: {'ms': [], 'rate': []} for v in variants}
-    for rnd in range(6):
+    for rnd in range(5):
         for v in variants:
-            env, _ = envs[v]
-            env.profile_begin(64, classes=('state',))
-            n, dt = window(env)
-            ms, cnt = env.profile_end()['state']
-            results[v]['ms'].append(ms / max(cnt, 1))
-            results[v]['rate'].append(n / dt)
+            for env, _ in envs[v]:
+                env.profile_begin(64, classes=('state',))
+                n, dt = window(env)
+                ms, cnt = env.profile_end()['state']
+                results[v]['ms'].append(ms / max(cnt, 1))
+                results[v]['rate'].append(n / dt)
     for v in variants:
         r = results[v]
+        per_copy = [float(np.median(r['ms'][c::copies])) for c in range(copies)]
         print(json.dumps({'variant': v, 'k_state_ms_median': float(np.median(r['ms'])),
-                          'k_state_ms_min': float(np.min(r['ms'])),
+                          'k_state_ms_per_instance': per_copy,
                           'Msteps_per_s_median': float(np.median(r['rate'])) / 1e6,
-                          'max_abs_diff_vs_first': envs[v][1]}), flush=True)
+                          'max_abs_diff_vs_first': max(d for _, d in envs[v])}), flush=True)
 
 
 if __name__ == '__main__':

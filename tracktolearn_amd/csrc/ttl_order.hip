@@ -85,7 +85,7 @@ int ttl_detail_refresh_order(const EnvParams &P, const int *idx, int n, char *ws
     // TTL_ORDER_KEY: bit 0 = voxel-level keys (brick, then Morton code of the
     // voxel inside the brick), bit 1 = Morton order of the bricks themselves
     // instead of the dense x-major brick index
-    int fine = 2;
+    int fine = 0;     // measured: neither bit pays once k_proc_scatter re-sorts locally
     if (const char *v = getenv("TTL_ORDER_KEY")) fine = atoi(v) & 3;
     if (fine & 2) {
         int mx = nb[0] > nb[1] ? nb[0] : nb[1];

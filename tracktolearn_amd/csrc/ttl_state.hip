@@ -512,365 +512,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_prefix_state(
                                          out + (size_t)dest * (size_t)pitch);
 }
 
-// ---------------------------------------------------------------------------
-// k_state_dd2: the same gather as k_state_dd, scheduled for memory-level
-// parallelism.  gfx950 has ONE vector-memory counter (vmcnt) that loads and
-// stores share and that completes in order: in k_state_dd every axis stores its
-// points before the next axis' outer slices are fetched, so each of the up to
-// seven dependent fetch groups is waited for with vmcnt(0) *behind the stores
-// issued before it* -- a wave keeps 4 loads in flight and pays a store
-// acknowledgement (an HBM write, microseconds under load) per round trip.
-// Here a wave issues its fetches in SCHED-many large groups and not a single
-// load is waited for after a store: all seven points are stored at the end.
-//   SCHED 0: [centre + x slices] -> x points | [y + z slices] -> y, z points
-//   SCHED 1: [centre + x + y slices] -> x | [z slices] -> y -> z   (pipelined)
-//   SCHED 2: everything up front
-// PARK: the points computed before the last fetch group wait in LDS (one
-// float4 per thread and point, no barrier: a lane reads back what it wrote)
-// instead of in registers.  Arithmetic is contracted to FMAs here (the state is
-// compared at 1e-5, not bit for bit; the direction block is plain differences
-// of stored float32 positions and is not affected).
-// ---------------------------------------------------------------------------
-struct arm4 {
-    f4 a, b, c, d;
-};
-__device__ __forceinline__ arm4 load_arm(const char *vol, unsigned o0, unsigned o1,
-                                         unsigned o2, unsigned o3, bool on) {
-    arm4 r;     // left unset where the slice is not needed: only read under `on`
-    if (on) {
-        r.a = ld4(vol, o0);
-        r.b = ld4(vol, o1);
-        r.c = ld4(vol, o2);
-        r.d = ld4(vol, o3);
-    }
-    return r;
-}
-__device__ __forceinline__ f4 blend_arm(const arm4 &r, bool on, float a0, float a1,
-                                        float b0, float b1) {
-    f4 b{0.f, 0.f, 0.f, 0.f};
-    if (on) b = blend4(r.a, r.b, r.c, r.d, a0, a1, b0, b1);
-    return b;
-}
-
-template <int LPS, int MINW, bool MERGE_TAIL, int SCHED, bool PARK>
-__global__ __launch_bounds__(BLOCK, MINW) void k_state_dd2(
-    EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
-    const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
-    long long pitch) {
-#pragma clang fp contract(fast)
-    constexpr int GPW = 64 / LPS;
-    constexpr int ROWS = (BLOCK / 64) * GPW;
-    __shared__ f4 park[PARK ? 5 : 1][PARK ? BLOCK : 1];
-    int blk = blockIdx.x;
-    if (proc && P.xcd_remap) {
-        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = blk & 7;
-        blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blk >> 3);
-    }
-    const int lane = threadIdx.x & 63;
-    const int grp = lane / LPS;
-    const int slot = blk * ROWS + (threadIdx.x >> 6) * GPW + grp;
-    const int sub = lane - grp * LPS;
-    if (grp >= GPW || slot >= n_rows) return;
-    int row, g, r;
-    float px, py, pz;
-    const bool slot_records = proc && idx && P.slot_rec;
-    if (slot_records) {
-        const float4 hp = *reinterpret_cast<const float4 *>(P.slot_head + 4 * (size_t)slot);
-        px = hp.x;
-        py = hp.y;
-        pz = hp.z;
-        g = __float_as_int(hp.w);
-        r = P.slot_dest[slot];
-        row = 0;
-    } else {
-        row = proc ? proc[slot] : slot;
-        g = idx ? idx[row] : row;
-        r = row_dest ? row_dest[row] : row;
-    }
-    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
-    if (slot_records) {
-    } else if (idx) {
-        const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
-        px = hp.x;
-        py = hp.y;
-        pz = hp.z;
-    } else {
-        px = h[(L - 1) * 3 + 0];
-        py = h[(L - 1) * 3 + 1];
-        pz = h[(L - 1) * 3 + 2];
-    }
-    // this lane's direction segment: the two points are fetched now (a
-    // scattered sector of the history), subtracted after the gather
-    const int n_seg = L - 1;
-    const bool has_seg = sub < P.n_dirs && sub < n_seg;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
-    if (has_seg) {
-        const float *a = h + (L - 2 - sub) * 3;
-        a0 = a[0]; a1 = a[1]; a2 = a[2];
-        a3 = a[3]; a4 = a[4]; a5 = a[5];
-    }
-    float *orow = out + (size_t)r * (size_t)pitch;
-    const int C = P.n_coef;
-    const int C4 = P.coef_pitch >> 2;
-    const int X = P.sh_dim[0], Y = P.sh_dim[1], Z = P.sh_dim[2];
-    const char *vol = reinterpret_cast<const char *>(P.sh);
-    const float rad = P.radius;
-
-    float cxp = px + rad, cxm = px + (-rad);
-    float cyp = py + rad, cym = py + (-rad);
-    float czp = pz + rad, czm = pz + (-rad);
-    if (P.sh_shift != 0.0f) {
-        px += P.sh_shift; py += P.sh_shift; pz += P.sh_shift;
-        cxp += P.sh_shift; cxm += P.sh_shift;
-        cyp += P.sh_shift; cym += P.sh_shift;
-        czp += P.sh_shift; czm += P.sh_shift;
-    }
-    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-    const float dx = px - fx, dy = py - fy, dz = pz - fz;
-    const float ex = 1.0f - dx, ey = 1.0f - dy, ez = 1.0f - dz;
-    const float fxp = floorf(cxp), fxm = floorf(cxm);
-    const float fyp = floorf(cyp), fym = floorf(cym);
-    const float fzp = floorf(czp), fzm = floorf(czm);
-    const float dxp = cxp - fxp, dxm = cxm - fxm;
-    const float dyp = cyp - fyp, dym = cym - fym;
-    const float dzp = czp - fzp, dzm = czm - fzm;
-    const bool xup = fxp > fx, xdn = fxm < fx;
-    const bool yup = fyp > fy, ydn = fym < fy;
-    const bool zup = fzp > fz, zdn = fzm < fz;
-    const int ix = (int)fminf(fmaxf(fx, -4.0f), (float)X + 4.0f);
-    const int iy = (int)fminf(fmaxf(fy, -4.0f), (float)Y + 4.0f);
-    const int iz = (int)fminf(fmaxf(fz, -4.0f), (float)Z + 4.0f);
-    const unsigned rec = (unsigned)C4 * 16u;
-    const unsigned cb = (unsigned)sub * 16u;       // this lane's column
-    const unsigned x0 = vox_x(P, clipi(ix - 1, X)) * rec + cb, x1 = vox_x(P, clipi(ix, X)) * rec + cb,
-                   x2 = vox_x(P, clipi(ix + 1, X)) * rec + cb, x3 = vox_x(P, clipi(ix + 2, X)) * rec + cb;
-    const unsigned y0 = vox_y(P, clipi(iy - 1, Y)) * rec, y1 = vox_y(P, clipi(iy, Y)) * rec,
-                   y2 = vox_y(P, clipi(iy + 1, Y)) * rec, y3 = vox_y(P, clipi(iy + 2, Y)) * rec;
-    const unsigned z0 = vox_z(P, clipi(iz - 1, Z)) * rec, z1 = vox_z(P, clipi(iz, Z)) * rec,
-                   z2 = vox_z(P, clipi(iz + 1, Z)) * rec, z3 = vox_z(P, clipi(iz + 2, Z)) * rec;
-    const bool col = sub < C4;          // lanes beyond the record fetch nothing
-    const int c = sub * 4;
-#define TTL_VOX(xo, yo, zo) ((xo) + (yo) + (zo))
-    const f4 zero{0.f, 0.f, 0.f, 0.f};
-    f4 v000 = zero, v001 = zero, v010 = zero, v011 = zero;
-    f4 v100 = zero, v101 = zero, v110 = zero, v111 = zero;
-    if (col) {
-        v000 = ld4(vol, TTL_VOX(x1, y1, z1)); v001 = ld4(vol, TTL_VOX(x1, y1, z2));
-        v010 = ld4(vol, TTL_VOX(x1, y2, z1)); v011 = ld4(vol, TTL_VOX(x1, y2, z2));
-        v100 = ld4(vol, TTL_VOX(x2, y1, z1)); v101 = ld4(vol, TTL_VOX(x2, y1, z2));
-        v110 = ld4(vol, TTL_VOX(x2, y2, z1)); v111 = ld4(vol, TTL_VOX(x2, y2, z2));
-    }
-    // outer slices, fetched only where a shifted point really reaches them
-#define TTL_XARMS                                                                     \
-    const arm4 xa0 = load_arm(vol, TTL_VOX(x0, y1, z1), TTL_VOX(x0, y1, z2),          \
-                              TTL_VOX(x0, y2, z1), TTL_VOX(x0, y2, z2), col && xdn);  \
-    const arm4 xa3 = load_arm(vol, TTL_VOX(x3, y1, z1), TTL_VOX(x3, y1, z2),          \
-                              TTL_VOX(x3, y2, z1), TTL_VOX(x3, y2, z2), col && xup);
-#define TTL_YARMS                                                                     \
-    const arm4 ya0 = load_arm(vol, TTL_VOX(x1, y0, z1), TTL_VOX(x1, y0, z2),          \
-                              TTL_VOX(x2, y0, z1), TTL_VOX(x2, y0, z2), col && ydn);  \
-    const arm4 ya3 = load_arm(vol, TTL_VOX(x1, y3, z1), TTL_VOX(x1, y3, z2),          \
-                              TTL_VOX(x2, y3, z1), TTL_VOX(x2, y3, z2), col && yup);
-#define TTL_ZARMS                                                                     \
-    const arm4 za0 = load_arm(vol, TTL_VOX(x1, y1, z0), TTL_VOX(x1, y2, z0),          \
-                              TTL_VOX(x2, y1, z0), TTL_VOX(x2, y2, z0), col && zdn);  \
-    const arm4 za3 = load_arm(vol, TTL_VOX(x1, y1, z3), TTL_VOX(x1, y2, z3),          \
-                              TTL_VOX(x2, y1, z3), TTL_VOX(x2, y2, z3), col && zup);
-    TTL_XARMS
-#define TTL_XPOINTS                                                                   \
-    f4 o0, o1, o4;                                                                    \
-    {                                                                                 \
-        const f4 b0 = blend_arm(xa0, col && xdn, ey, dy, ez, dz),                           \
-                 b3 = blend_arm(xa3, col && xup, ey, dy, ez, dz);                           \
-        ; \
-        const f4 b1 = blend4(v000, v001, v010, v011, ey, dy, ez, dz);                 \
-        const f4 b2 = blend4(v100, v101, v110, v111, ey, dy, ez, dz);                 \
-        o0 = lerp4(b1, b2, dx);                                                       \
-        o1 = lerp4(sel4(xup, b2, b1), sel4(xup, b3, b2), dxp);                        \
-        o4 = lerp4(sel4(xdn, b0, b1), sel4(xdn, b1, b2), dxm);                        \
-    }
-#define TTL_YPOINTS                                                                   \
-    f4 o2, o5;                                                                        \
-    {                                                                                 \
-        const f4 b0 = blend_arm(ya0, col && ydn, ex, dx, ez, dz),                           \
-                 b3 = blend_arm(ya3, col && yup, ex, dx, ez, dz);                           \
-        ; \
-        const f4 b1 = blend4(v000, v001, v100, v101, ex, dx, ez, dz);                 \
-        const f4 b2 = blend4(v010, v011, v110, v111, ex, dx, ez, dz);                 \
-        o2 = lerp4(sel4(yup, b2, b1), sel4(yup, b3, b2), dyp);                        \
-        o5 = lerp4(sel4(ydn, b0, b1), sel4(ydn, b1, b2), dym);                        \
-    }
-#define TTL_ZPOINTS                                                                   \
-    f4 o3, o6;                                                                        \
-    {                                                                                 \
-        const f4 b0 = blend_arm(za0, col && zdn, ex, dx, ey, dy),                           \
-                 b3 = blend_arm(za3, col && zup, ex, dx, ey, dy);                           \
-        ; \
-        const f4 b1 = blend4(v000, v010, v100, v110, ex, dx, ey, dy);                 \
-        const f4 b2 = blend4(v001, v011, v101, v111, ex, dx, ey, dy);                 \
-        o3 = lerp4(sel4(zup, b2, b1), sel4(zup, b3, b2), dzp);                        \
-        o6 = lerp4(sel4(zdn, b0, b1), sel4(zdn, b1, b2), dzm);                        \
-    }
-    // compiler fence between fetch groups: the points of the finished group
-    // are computed (their inputs' registers die) before the next group's loads
-    // may issue; without it the compiler hoists all 32 loads to the top
-#define TTL_FENCE(p, q, r)                                                            \
-    asm volatile("" : "+v"(p.x), "+v"(q.x), "+v"(r.x) : : "memory");
-#define TTL_PARK_X                                                                    \
-    if (PARK) {                                                                       \
-        park[0][threadIdx.x] = o0;                                                    \
-        park[1][threadIdx.x] = o1;                                                    \
-        park[2][threadIdx.x] = o4;                                                    \
-    }
-#define TTL_UNPARK_X                                                                  \
-    if (PARK) {                                                                       \
-        o0 = park[0][threadIdx.x];                                                    \
-        o1 = park[1][threadIdx.x];                                                    \
-        o4 = park[2][threadIdx.x];                                                    \
-    }
-    if (SCHED == 0) {
-        TTL_XPOINTS
-        TTL_FENCE(o0, o1, o4)
-        TTL_PARK_X
-        TTL_YARMS
-        TTL_ZARMS
-        TTL_YPOINTS
-        TTL_ZPOINTS
-        TTL_UNPARK_X
-        if (col) {
-            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
-        }
-    } else if (SCHED == 1) {
-        TTL_YARMS
-        TTL_XPOINTS
-        TTL_FENCE(o0, o1, o4)
-        TTL_PARK_X
-        TTL_ZARMS
-        TTL_YPOINTS
-        TTL_ZPOINTS
-        TTL_UNPARK_X
-        if (col) {
-            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
-        }
-    } else if (SCHED == 3) {
-        // three fetch groups of at most 16 / 8 / 8 records, one axis each
-        TTL_XPOINTS
-        TTL_FENCE(o0, o1, o4)
-        TTL_PARK_X
-        TTL_YARMS
-        TTL_YPOINTS
-        TTL_FENCE(o2, o5, o5)
-        if (PARK) {
-            park[3][threadIdx.x] = o2;
-            park[4][threadIdx.x] = o5;
-        }
-        TTL_ZARMS
-        TTL_ZPOINTS
-        TTL_UNPARK_X
-        if (PARK) {
-            o2 = park[3][threadIdx.x];
-            o5 = park[4][threadIdx.x];
-        }
-        if (col) {
-            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
-        }
-    } else {
-        TTL_YARMS
-        TTL_ZARMS
-        TTL_XPOINTS
-        TTL_YPOINTS
-        TTL_ZPOINTS
-        if (col) {
-            put4<MERGE_TAIL>(P.store_flavour, orow + 0 * C + c, o0, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 1 * C + c, o1, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 2 * C + c, o2, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 3 * C + c, o3, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 4 * C + c, o4, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 5 * C + c, o5, c, C);
-            put4<MERGE_TAIL>(P.store_flavour, orow + 6 * C + c, o6, c, C);
-        }
-    }
-#undef TTL_VOX
-#undef TTL_XARMS
-#undef TTL_YARMS
-#undef TTL_ZARMS
-#undef TTL_XPOINTS
-#undef TTL_YPOINTS
-#undef TTL_ZPOINTS
-#undef TTL_PARK_X
-#undef TTL_FENCE
-#undef TTL_UNPARK_X
-    // previous directions, most recent first, zero padded
-    float *od = orow + 7 * C;
-    if (sub < P.n_dirs) {
-        od[3 * sub + 0] = a3 - a0;
-        od[3 * sub + 1] = a4 - a1;
-        od[3 * sub + 2] = a5 - a2;
-    }
-    for (int j = sub + LPS; j < P.n_dirs; j += LPS) {   // K > lane group size
-        float vx = 0.0f, vy = 0.0f, vz = 0.0f;
-        if (j < n_seg) {
-            const float *a = h + (L - 2 - j) * 3;
-            const float ax = a[0], ay = a[1], az = a[2];
-            const float bx = a[3], by = a[4], bz = a[5];
-            vx = bx - ax;
-            vy = by - ay;
-            vz = bz - az;
-        }
-        od[3 * j + 0] = vx;
-        od[3 * j + 1] = vy;
-        od[3 * j + 2] = vz;
-    }
-}
-
 }  // namespace
-
-// state_kernel = 10 + 4 * SCHED + 2 * PARK + (3 waves/SIMD ? 1 : 0)
-template <int LPS>
-static void launch_dd2(int state_kernel, dim3 grid, hipStream_t s, const EnvParams &P,
-                       const int *idx, const int *row_dest, const int *proc, int n_rows,
-                       int L, float *out, long long pitch) {
-    const int v = state_kernel - 10;
-#define TTL_DD2(SCHED, PARK, MINW)                                                       \
-    hipLaunchKernelGGL((k_state_dd2<LPS, MINW, true, SCHED, PARK>), grid, dim3(BLOCK), 0, s, \
-                       P, idx, row_dest, proc, n_rows, L, out, pitch)
-    switch (v) {
-        case 0: TTL_DD2(0, false, 4); break;
-        case 1: TTL_DD2(0, false, 3); break;
-        case 2: TTL_DD2(0, true, 4); break;
-        case 3: TTL_DD2(0, true, 3); break;
-        case 4: TTL_DD2(1, false, 4); break;
-        case 5: TTL_DD2(1, false, 3); break;
-        case 6: TTL_DD2(1, true, 4); break;
-        case 7: TTL_DD2(1, true, 3); break;
-        case 8: TTL_DD2(2, false, 4); break;
-        case 9: TTL_DD2(2, false, 3); break;
-        case 12: TTL_DD2(3, false, 4); break;
-        case 13: TTL_DD2(3, false, 3); break;
-        case 14: TTL_DD2(3, true, 4); break;
-        case 15: TTL_DD2(3, true, 3); break;
-        default: TTL_DD2(2, false, 2); break;
-    }
-#undef TTL_DD2
-}
 
 // The fused small-batch tail (k_prefix_state) applies when the deduplicated
 // gather does, the record fits one lane group of 4..16 lanes and the batch has
@@ -921,9 +563,6 @@ int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx
             hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, P, \
                                idx, row_dest, proc, n_rows, L, out,           \
                                (long long)pitch);                             \
-        else if (LPS < 32 && P.n_coef >= 4 && state_kernel >= 10)                 \
-            launch_dd2<LPS>(state_kernel, grid, s, P, idx, row_dest, proc, n_rows, L, out, \
-                            (long long)pitch);                                \
         else if (LPS < 32 && P.n_coef >= 4 && state_kernel != 3)    \
             hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32), (LPS < 32)>), grid, dim3(BLOCK), 0, s, \
                                P, idx, row_dest, proc, n_rows, L, out,   \
