@@ -1,6 +1,9 @@
 #!/bin/bash
 # The judged profile set, from one box and one invocation:
 #   gpurun --timeout 900 -- 'bash profiles/collect.sh r01'
+# (profiled passes run `bench.py --no-cpu-baseline --no-whole-episode`: the same timed
+#  windows, without the forked CPU workers and without the episode-to-exhaustion tail whose
+#  small launches would dilute the per-kernel averages)
 # 1. bench.py alone            -> profiles/<tag>_bench.json
 # 2. rocprofv3 --kernel-trace --stats of the same command
 #                               -> profiles/<tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json
@@ -17,9 +20,9 @@ export TMPDIR=/tmp
 O=gpurun_out/prof_$tag
 mkdir -p $O
 T="timeout -k 10 400"
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log
-$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --no-cpu-baseline > /dev/null 2> $O/fetch.log
-$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --no-cpu-baseline > /dev/null 2> $O/write.log
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/bench_under_rocprof.json 2> $O/stats.log
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --no-cpu-baseline --no-whole-episode > /dev/null 2> $O/fetch.log
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --no-cpu-baseline --no-whole-episode > /dev/null 2> $O/write.log
 python3 profiles/pmc_summary.py $tag $O/stats $O/fetch $O/write
 $T python3 bench.py > $O/bench.json
 R=gpurun_out/profiles_$tag

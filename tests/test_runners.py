@@ -321,3 +321,44 @@ def test_ttl_track_from_hdf5_end_to_end(tmp_path):
     assert out.endswith('tractogram_toy_v1_sub-b.tck')
     tck, fields = sio.load_tck(out)
     assert int(fields['count']) == len(tck) > 50
+
+
+def _last_json_line(text):
+    rows = [r for r in text.splitlines() if r.startswith('{') and '"metric"' in r]
+    assert rows, text[-2000:]
+    return json.loads(rows[-1])
+
+
+def test_bench_self_launch_reports_failed_ranks():
+    """`python bench.py --gpus 2` without a launcher starts its ranks itself;
+    here (no GPU) the ranks fail, and the parent must come back with a
+    non-zero exit code instead of a line or a hang."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                          '--windows', '1', '--no-cpu-baseline', '--no-whole-episode'],
+                         capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES='',
+                                  HIP_VISIBLE_DEVICES=''))
+    assert out.returncode != 0
+    assert '"metric"' not in out.stdout
+    assert 'failed' in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The N > 1 path of bench.py as far as a 1-GPU box can take it: the bare
+    `--gpus 2` call launches two ranks itself (both on cuda:0, gloo instead of
+    RCCL, which refuses two ranks on one device), shards, times the windows,
+    gathers the finished tracts to rank 0 and prints ONE line."""
+    env = dict(os.environ, PYTHONPATH=ROOT, TTL_BENCH_ONE_DEVICE='1',
+               TTL_BENCH_BACKEND='gloo')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                          '--windows', '3', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _last_json_line(out.stdout)
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak'
+    assert line['streamline_steps'] > 2 * 12 * 200000          # both shards counted
+    assert line['collate_ms'] > 0 and line['collate_bytes_to_root'] > 0
+    assert 'collate_error' not in line
+    assert line['windows']['n'] == 3
+    assert line['roofline']['frac'] is None or line['roofline']['frac'] <= 1.0
