@@ -579,9 +579,14 @@ def test_episode_on_a_non_default_stream():
         TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved_refresh
 
 
-def test_caller_supplied_processing_orders_change_nothing():
+@pytest.mark.parametrize('fused,sorter', [('0', '1'), ('1', '1'), ('0', '0')])
+def test_caller_supplied_processing_orders_change_nothing(fused, sorter, monkeypatch):
     """ttl_env_set_processing_order with arbitrary permutations between steps
-    (and the library's own refresh in between): a scheduling hint only."""
+    (and the library's own refresh in between -- counting sort or rocPRIM):
+    a scheduling hint only.  With the fused tail on, a batch this small drops
+    the order again at its next step."""
+    monkeypatch.setenv('TTL_FUSE_SMALL', fused)
+    monkeypatch.setenv('TTL_ORDER_SORT', sorter)
     from oracle import env_oracle as orc
     from tracktolearn_amd import _lib
     from tracktolearn_amd.environments import TrackingEnvironment

@@ -1211,8 +1211,11 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         HIP_TRY(hipGetLastError());
     }
     // a few thousand streamlines fit the caches in any order: stop paying for
-    // the processing order in the episode's tail
-    if (env->use_proc && n_active < 8192) env->use_proc = 0;
+    // the processing order in the episode's tail (from 16 384 rows down the
+    // one-launch tail below takes over)
+    if (env->use_proc && (n_active < 8192 ||
+                          (env->fuse_small && ttl_detail_can_fuse_tail(env->P, n_active))))
+        env->use_proc = 0;
     const int *proc = env->use_proc ? env->proc[env->proc_cur] : nullptr;
     env->stepped = 1;
     env->last_order = order;
