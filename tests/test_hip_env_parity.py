@@ -343,6 +343,48 @@ def test_edge_cases():
     assert env.get_state_size() == 7 * 45 + 12
 
 
+@pytest.mark.parametrize('N', [1, 255, 256, 257, 5000, 16384, 16385, 20000])
+def test_fused_and_three_launch_tails_agree_at_the_batch_boundaries(N, monkeypatch):
+    """The one-launch tail (batches <= 64 x 256 rows) against the three-launch
+    path on the same inputs, around the workgroup, wave and path boundaries:
+    identical rows, indices, flags and counts, in both row orders, with both
+    record orders of the packed SH volume (dims not multiples of 4)."""
+    D = 13
+    sh, mask, pk = synthetic_subject(D)
+    rng = np.random.RandomState(N)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    acts = [rng.standard_normal((N, 3)).astype(np.float32) for _ in range(3)]
+    runs = {}
+    for fused, layout in (('1', 'brick4'), ('0', 'brick4'), ('1', 'linear'), ('0', 'linear')):
+        monkeypatch.setenv('TTL_FUSE_SMALL', fused)
+        monkeypatch.setenv('TTL_SH_LAYOUT', layout)
+        env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds, n_dirs=4,
+                       max_length=20.0, reward=True)
+        out = [env.reset(0, N).cpu().numpy()]
+        for step in range(3):
+            n = env._n_active
+            if n == 0:
+                break
+            a = torch.from_numpy(acts[step][:n]).cuda()
+            if step % 2 == 0:
+                ns, rew, done, info = env.step_device(a)
+                out += [ns[info['row_dest'].long()].cpu().numpy(), rew.cpu().numpy(),
+                        done.cpu().numpy()]
+            else:
+                ns, rew, done, info = env.step(a)
+                out += [ns.cpu().numpy(), rew, done.astype(np.uint8)]
+            state, _ = env.harvest()
+            out += [state.cpu().numpy(), env.continue_idx.copy()]
+        out += [env.flags.copy(), env.lengths.copy(), env.streamlines.copy()]
+        runs[(fused, layout)] = out
+    first = runs[('1', 'brick4')]
+    for key, other in runs.items():
+        assert len(other) == len(first), key
+        for x, y in zip(first, other):
+            assert np.array_equal(x, y, equal_nan=True), key
+
+
 def _anisotropic_subject(shape, C=45, seed=77):
     """Non-cubic volumes: catches any x/y/z stride mix-up."""
     from tracktolearn_amd.datasets.utils import MRIDataVolume as Vol
