@@ -1,7 +1,7 @@
 #!/bin/bash
 # whole-episode rate against the period of the global order refresh
 cd "${GRAFT_REPO_ROOT:-.}"
-for r in 0 8 16 32; do
+for r in ${REFRESH_PERIODS:-0 8 16 32}; do
   TTL_ORDER_REFRESH=$r timeout -k 10 120 python3 bench.py --no-cpu-baseline --windows 3 | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
