@@ -80,11 +80,11 @@ def main():
             env, state = make(v, subject)
             # correctness: first 3 steps' rows against the first variant of the
             # same volume size
-            rows = [state.clone()]
+            rows = [state.contiguous().clone()]
             for step in range(3):
                 a = env.scripted_actions(state, step, 1, bench.WOBBLE)
                 ns, _, _, info = env.step_device(a)
-                rows.append(ns[info['row_dest'].long()].clone())
+                rows.append(ns[info['row_dest'].long()].contiguous().clone())
                 state, _ = env.harvest()
             d = parse(v)['d']
             if d not in ref_states:

@@ -59,9 +59,27 @@ def test_ttl_track_config1_end_to_end(tmp_path):
     from tracktolearn_amd.runners import ttl_track
     from tracktolearn_amd.tractogram import streamline_length
     paths, aff = _write_inputs(tmp_path)
-    # K = 100 previous directions: the shipped model's hyper-parameters
-    # (W = 615)
-    agent_dir, hp = _write_agent(tmp_path, 7 * 45 + 3 * 100, n_dirs=100)
+    # the shipped model's own hyperparameters.json (a data file of the
+    # reference, models/hyperparameters.json: K = 100 previous directions,
+    # W = 615, hidden 1024-1024-1024, voxel_size "0.9987237", step 0.75) with
+    # random weights of that architecture (the trained .pth files are not part
+    # of the reference tree)
+    import shutil
+    import torch
+    from tracktolearn_amd.algorithms.shared.offpolicy import SACActorCritic
+    shipped = json.loads(open(os.path.join(ROOT, 'tests', 'golden',
+                                           'reference_model_hyperparameters.json')).read())
+    assert shipped['input_size'] == 7 * 45 + 3 * shipped['n_dirs'] == 615
+    torch.manual_seed(3)
+    agent = SACActorCritic(shipped['input_size'], 3, shipped['hidden_dims'],
+                           torch.device('cpu'))
+    agent_dir = tmp_path / 'model'
+    agent_dir.mkdir()
+    agent.save(str(agent_dir), 'last_model_state')
+    hp = str(agent_dir / 'hyperparameters.json')
+    shutil.copy(os.path.join(ROOT, 'tests', 'golden',
+                             'reference_model_hyperparameters.json'), hp)
+    agent_dir = str(agent_dir)
     out = str(tmp_path / 'out.trk')
     argv = [paths['odf'], paths['seed'], paths['mask'], out, '--agent', agent_dir,
             '--hyperparameters', hp, '--n_actor', '4096', '--npv', '1',
@@ -123,6 +141,23 @@ def test_ttl_track_rescales_the_step_to_the_subject_voxel_size(tmp_path, monkeyp
     for s in tg.streamlines[:200]:
         seg = np.linalg.norm(np.diff(s, axis=0), axis=1)
         assert np.abs(seg - 0.375).max() < 1e-4
+
+
+def test_shipped_hyperparameters_file_is_understood(tmp_path):
+    """ttl_track.py's constructor reads the reference's own
+    models/hyperparameters.json (string voxel size, float SH order, three
+    hidden layers) as runners/ttl_track.py:73-101 of the reference does."""
+    from tracktolearn_amd.runners.ttl_track import TrackToLearnTrack
+    hp = os.path.join(ROOT, 'tests', 'golden', 'reference_model_hyperparameters.json')
+    exp = TrackToLearnTrack(dict(
+        in_odf='a', in_seed='b', in_mask='c', out_tractogram='o.trk', noise=0.0,
+        binary_stopping_threshold=0.1, n_actor=4096, npv=1, min_length=10.,
+        max_length=300., compress=None, sh_basis='descoteaux07', save_seeds=False,
+        agent=str(tmp_path), hyperparameters=hp, rng_seed=1337))
+    assert exp.algorithm == 'SACAuto' and exp.n_dirs == 100
+    assert exp.hidden_dims == '1024-1024-1024' and exp.step_size == 0.75
+    assert abs(float(exp.voxel_size) - 0.9987237) < 1e-9 and exp.theta == 30
+    assert int(exp.target_sh_order) == 8
 
 
 def test_set_sh_order_basis_orders_and_fullness():

@@ -250,6 +250,8 @@ class BaseEnv(object):
         self._destroy_handle()
         self._n_max = 0
         self._state_width = 7 * C_ + 3 * int(self.n_dirs)
+        #: floats between consecutive state rows (= the width: contiguous rows)
+        self._state_pitch = self._state_width
 
     # ------------------------------------------------------------------ #
     def _tracking_params_key(self):
@@ -283,6 +285,14 @@ class BaseEnv(object):
         else:
             self._mode = _lib.MODE_F32
         self._loaded_params_key = self._tracking_params_key()
+
+    def _new_state(self, n):
+        """(n, state width) float32 rows on the device, `_state_pitch` apart."""
+        if self._state_pitch == self._state_width:
+            return torch.empty((n, self._state_width), dtype=torch.float32,
+                               device=self.device)
+        return torch.empty((n, self._state_pitch), dtype=torch.float32,
+                           device=self.device)[:, :self._state_width]
 
     def _stream(self):
         """Raw HIP stream torch currently launches on for this device (the

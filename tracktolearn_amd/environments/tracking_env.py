@@ -70,15 +70,14 @@ class TrackingEnvironment(BaseEnv):
         seeds32 = torch.from_numpy(
             np.ascontiguousarray(initial_points, dtype=np.float32)
         ).to(self.device)
-        state = torch.empty((n, self._state_width), dtype=torch.float32,
-                            device=self.device)
+        state = self._new_state(n)
         # batches of SPATIAL_ORDER_MIN rows and more are gathered in a
         # spatially sorted processing order (built by the library)
         sort_rows = n >= self.SPATIAL_ORDER_MIN and getattr(self, 'spatial_order', True)
         _lib.check(self._lib.ttl_env_reset(
             self._handle, seeds32.data_ptr(), n,
             _lib.ORDER_BY_POSITION if sort_rows else None, state.data_ptr(),
-            self._state_width, self._stream()), 'ttl_env_reset')
+            self._state_pitch, self._stream()), 'ttl_env_reset')
         self._n_total = n
         self._n_active = n
         self._cur = 0
@@ -151,8 +150,7 @@ class TrackingEnvironment(BaseEnv):
         a = self._actions_to_device(actions)
         noise = self._noise_for(a)
         self._refresh_processing_order()
-        state = torch.empty((n, self._state_width), dtype=torch.float32,
-                            device=self.device)
+        state = self._new_state(n)
         done = torch.empty(n, dtype=torch.uint8, device=self.device)
         reward = None
         if self.compute_reward:
@@ -162,7 +160,7 @@ class TrackingEnvironment(BaseEnv):
         if not self._use_oracle_stopping:
             _lib.check(self._lib.ttl_env_step(
                 self._handle, a.data_ptr(), noise_ptr, n, order,
-                state.data_ptr(), self._state_width, reward_ptr,
+                state.data_ptr(), self._state_pitch, reward_ptr,
                 done.data_ptr(), self._host_counts.data_ptr(), self._stream()),
                 'ttl_env_step')
         else:
@@ -175,7 +173,7 @@ class TrackingEnvironment(BaseEnv):
             extra = self._oracle_stopping_flags(n, self.length + 1)
             _lib.check(self._lib.ttl_env_step_end(
                 self._handle, extra.data_ptr() if extra is not None else None,
-                order, state.data_ptr(), self._state_width,
+                order, state.data_ptr(), self._state_pitch,
                 self._host_counts.data_ptr(), self._stream()),
                 'ttl_env_step_end')
             self._keep_alive = extra
@@ -288,10 +286,10 @@ class TrackingEnvironment(BaseEnv):
         state_in = pend['state']
         out = None
         if order == _lib.ORDER_ACTIVE:
-            out = torch.empty_like(state_in)
+            out = self._new_state(state_in.shape[0])
         _lib.check(self._lib.ttl_env_harvest(
             self._handle, state_in.data_ptr(),
-            out.data_ptr() if out is not None else None, self._state_width,
+            out.data_ptr() if out is not None else None, self._state_pitch,
             self._stream()), 'ttl_env_harvest')
         # the survivor count left the GPU right after the stopping decisions
         # (side stream): this wait does not cover the state gather
