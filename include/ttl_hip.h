@@ -254,7 +254,7 @@ int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
                                  void *hip_stream);
 
 /* The same, computed by the library: active rows sorted by the 8^3-voxel brick
- * of their streamline's newest point (key kernel + radix sort on workspace
+ * of their streamline's newest point (key kernel + counting sort on workspace
  * memory, no allocation).  Between a harvest and the next step, after the
  * survivor count has been read back. */
 int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream);

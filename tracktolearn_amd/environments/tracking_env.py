@@ -98,7 +98,9 @@ class TrackingEnvironment(BaseEnv):
     def _refresh_processing_order(self, force=False):
         """Every SPATIAL_ORDER_REFRESH steps: re-sort the active rows by where
         their streamlines are now (``ttl_env_refresh_processing_order``: a key
-        kernel + a radix sort inside the library, on workspace memory)."""
+        kernel + a counting sort over the bricks inside the library, on
+        workspace memory); in between, the library re-sorts every 256-slot
+        block of the order by current voxel at each step."""
         every = self.SPATIAL_ORDER_REFRESH
         n = self._n_active
         if n < self.SPATIAL_ORDER_MIN or self._pending is not None or \
