@@ -99,9 +99,11 @@ def main():
     for rnd in range(5):
         for v in variants:
             for env, _ in envs[v]:
-                env.profile_begin(64, classes=('state',))
+                env.profile_begin(64, classes=('state', 'advance'))
                 n, dt = window(env)
-                ms, cnt = env.profile_end()['state']
+                prof = env.profile_end()
+                ms, cnt = prof['state']
+                results[v].setdefault('adv', []).append(prof['advance'][0] / max(prof['advance'][1], 1))
                 results[v]['ms'].append(ms / max(cnt, 1))
                 results[v]['rate'].append(n / dt)
     for v in variants:
@@ -109,6 +111,7 @@ def main():
         per_copy = [float(np.median(r['ms'][c::copies])) for c in range(copies)]
         print(json.dumps({'variant': v, 'k_state_ms_median': float(np.median(r['ms'])),
                           'k_state_ms_per_instance': per_copy,
+                          'k_advance_ms_median': float(np.median(r['adv'])),
                           'Msteps_per_s_median': float(np.median(r['rate'])) / 1e6,
                           'max_abs_diff_vs_first': max(d for _, d in envs[v])}), flush=True)
 
