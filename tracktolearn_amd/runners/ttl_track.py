@@ -44,44 +44,42 @@ def per_rank_noise_rng(rng_seed, rank):
     return np.random.RandomState((int(rng_seed) + 1 + int(rank)) % (2 ** 32))
 
 
+#: track_dto keys copied onto the experiment as they are (argparse names)
+_PASS_THROUGH = ('in_odf', 'in_seed', 'in_mask', 'out_tractogram', 'noise',
+                 'binary_stopping_threshold', 'n_actor', 'npv', 'min_length',
+                 'max_length', 'sh_basis', 'save_seeds', 'agent', 'hyperparameters')
+
+#: hyperparameters.json key -> attribute (the file a training run writes,
+#: trainers/train.py; the shipped one is models/hyperparameters.json)
+_HYPER = {'algorithm': 'algorithm', 'max_angle': 'theta', 'hidden_dims': 'hidden_dims',
+          'n_dirs': 'n_dirs', 'target_sh_order': 'target_sh_order'}
+
+
 class TrackToLearnTrack(object):
-    """Tracking experiment (ttl_track.py:38-186 of the reference)."""
+    """Tracking experiment: the noisy env built from files, a trained SACAuto
+    policy, `Tracker.track`, a .trk / .tck file (runners/ttl_track.py:38-186 of
+    the reference: same track_dto keys, same order of the side effects on the
+    random generators)."""
 
     def __init__(self, track_dto):
-        self.in_odf = track_dto['in_odf']
-        self.in_seed = track_dto['in_seed']
-        self.in_mask = track_dto['in_mask']
+        for key in _PASS_THROUGH:
+            setattr(self, key, track_dto[key])
         self.input_wm = track_dto.get('input_wm', False)
-        self.reference_file = track_dto['in_mask']
-        self.out_tractogram = track_dto['out_tractogram']
-        self.noise = track_dto['noise']
-        self.binary_stopping_threshold = track_dto['binary_stopping_threshold']
-        self.n_actor = track_dto['n_actor']
-        self.npv = track_dto['npv']
-        self.min_length = track_dto['min_length']
-        self.max_length = track_dto['max_length']
+        self.reference_file = self.in_mask
         self.compress = track_dto['compress'] or 0.0
-        self.sh_basis = track_dto['sh_basis']
-        self.save_seeds = track_dto['save_seeds']
-        self.compute_reward = False
+        # tracking never computes rewards and never consults the oracle
+        self.compute_reward, self.alignment_weighting = False, 0.0
+        self.oracle_checkpoint, self.oracle_bonus = None, 0.0
+        self.oracle_stopping_criterion = False
+        self.fa_map = None
         self.device = torch.device('cuda', torch.cuda.current_device()) \
             if torch.cuda.is_available() else get_device()
-        self.fa_map = None
-        self.agent = track_dto['agent']
-        self.hyperparameters = track_dto['hyperparameters']
         with open(self.hyperparameters, 'r') as json_file:
-            hyperparams = json.load(json_file)
-            self.algorithm = hyperparams['algorithm']
-            self.step_size = float(hyperparams['step_size'])
-            self.voxel_size = hyperparams.get('voxel_size', 2.0)
-            self.theta = hyperparams['max_angle']
-            self.hidden_dims = hyperparams['hidden_dims']
-            self.n_dirs = hyperparams['n_dirs']
-            self.target_sh_order = hyperparams['target_sh_order']
-        self.alignment_weighting = 0.0
-        self.oracle_checkpoint = None
-        self.oracle_bonus = 0.0
-        self.oracle_stopping_criterion = False
+            hyper = json.load(json_file)
+        for key, attr in _HYPER.items():
+            setattr(self, attr, hyper[key])
+        self.step_size = float(hyper['step_size'])
+        self.voxel_size = hyper.get('voxel_size', 2.0)
         self.random_seed = track_dto['rng_seed']
         torch.manual_seed(self.random_seed)
         np.random.seed(self.random_seed)
@@ -89,69 +87,61 @@ class TrackToLearnTrack(object):
         self.rng = np.random.RandomState(seed=self.random_seed)
 
     def get_tracking_env(self):
-        """experiment.py:177-204: the noisy env, from files."""
-        env_dto = {
-            'dataset_file': None, 'fa_map': self.fa_map, 'n_dirs': self.n_dirs,
-            'step_size': self.step_size, 'theta': self.theta,
-            'min_length': self.min_length, 'max_length': self.max_length,
-            'noise': self.noise, 'npv': self.npv, 'rng': self.rng,
-            'alignment_weighting': self.alignment_weighting,
-            'oracle_bonus': self.oracle_bonus,
-            'oracle_stopping_criterion': self.oracle_stopping_criterion,
-            'oracle_checkpoint': self.oracle_checkpoint, 'scoring_data': None,
-            'binary_stopping_threshold': self.binary_stopping_threshold,
-            'compute_reward': self.compute_reward, 'device': self.device,
-            'target_sh_order': self.target_sh_order,
-            'in_odf': self.in_odf, 'in_seed': self.in_seed,
-            'in_mask': self.in_mask, 'sh_basis': self.sh_basis,
-            'input_wm': self.input_wm, 'reference': self.in_odf,
-        }
+        """The noisy env over the input files (experiment.py:177-204)."""
+        env_dto = {key: getattr(self, key) for key in (
+            'fa_map', 'n_dirs', 'theta', 'min_length', 'max_length', 'noise', 'npv',
+            'rng', 'alignment_weighting', 'oracle_bonus', 'oracle_stopping_criterion',
+            'oracle_checkpoint', 'binary_stopping_threshold', 'compute_reward',
+            'device', 'target_sh_order', 'in_odf', 'in_seed', 'in_mask', 'sh_basis',
+            'input_wm')}
+        env_dto.update(dataset_file=None, scoring_data=None, step_size=self.step_size,
+                       reference=self.in_odf)
         return NoisyTrackingEnvironment.from_files(env_dto)
+
+    def _step_for_subject(self, subject_voxel_size):
+        """Keep the number of voxels traversed per step of the training: an agent
+        trained at another voxel size steps proportionally (ttl_track.py:145-157)."""
+        trained = float(self.voxel_size)
+        if abs(float(subject_voxel_size) - trained) < 0.1:
+            return self.step_size
+        step_size_mm = float(subject_voxel_size) / trained * self.step_size
+        print('Agent was trained on a voxel size of {}mm and a step size '
+              'of {}mm.'.format(self.voxel_size, self.step_size))
+        print('Subject has a voxel size of {}mm, setting step size to '
+              '{}mm.'.format(subject_voxel_size, step_size_mm))
+        return step_size_mm
+
+    def _load_policy(self, env):
+        input_size = env.reset(0, 1).shape[1]
+        print('Tracking with {} agent.'.format(self.algorithm))
+        alg = {'SACAuto': SACAuto}[self.algorithm](
+            input_size, env.get_action_size(), self.hidden_dims, n_actors=self.n_actor,
+            rng=self.rng, device=self.device, replay_size=1)
+        alg.agent.load(self.agent, 'last_model_state')
+        return alg
 
     def run(self):
         ref_img = nifti.load(self.reference_file)
-        tracking_voxel_size = ref_img.get_zooms()[0]
-        # keep the "quantity" of voxels traversed per step of the training
-        step_size_mm = self.step_size
-        if abs(float(tracking_voxel_size) - float(self.voxel_size)) >= 0.1:
-            step_size_mm = (float(tracking_voxel_size) /
-                            float(self.voxel_size)) * self.step_size
-            print('Agent was trained on a voxel size of {}mm and a step size '
-                  'of {}mm.'.format(self.voxel_size, self.step_size))
-            print('Subject has a voxel size of {}mm, setting step size to '
-                  '{}mm.'.format(tracking_voxel_size, step_size_mm))
         env = self.get_tracking_env()
-        env.step_size_mm = step_size_mm
-
-        example_state = env.reset(0, 1)
-        self.input_size = example_state.shape[1]
-        self.action_size = env.get_action_size()
-
-        algs = {'SACAuto': SACAuto}
-        rl_alg = algs[self.algorithm]
-        print('Tracking with {} agent.'.format(self.algorithm))
-        alg = rl_alg(self.input_size, self.action_size, self.hidden_dims,
-                     n_actors=self.n_actor, rng=self.rng, device=self.device,
-                     replay_size=1)
-        alg.agent.load(self.agent, 'last_model_state')
-
+        env.step_size_mm = self._step_for_subject(ref_img.get_zooms()[0])
+        alg = self._load_policy(env)
         tracker = Tracker(alg, self.n_actor, compress=self.compress,
-                          min_length=self.min_length,
-                          max_length=self.max_length,
+                          min_length=self.min_length, max_length=self.max_length,
                           save_seeds=self.save_seeds)
+        # re-derives the step in voxels, the step counts and the neighbourhood
+        # radius from the rescaled step (environments/env.py:196-212)
         env.load_subject()
         if tracker.group_size > 1:
             env.noise_rng = per_rank_noise_rng(self.random_seed, tracker.rank)
-        filetype = detect_format(self.out_tractogram)
-        tractogram = tracker.track(env, filetype)
+        tractogram = tracker.track(env, detect_format(self.out_tractogram))
+        if tracker.rank != 0:
+            for _ in tractogram:        # take part in the collectives only
+                pass
+            return
         header = sio.create_tractogram_header(
             ref_img.affine, ref_img.shape[:3], ref_img.get_zooms()[:3])
-        if tracker.rank == 0:
-            n = sio.save(tractogram, self.out_tractogram, header=header)
-            print('Saved {} streamlines to {}'.format(n, self.out_tractogram))
-        else:
-            for _ in tractogram:        # take part in the collectives
-                pass
+        n = sio.save(tractogram, self.out_tractogram, header=header)
+        print('Saved {} streamlines to {}'.format(n, self.out_tractogram))
 
 
 def add_mandatory_options_tracking(p):
