@@ -185,16 +185,16 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
  *   reward_out[n_active] f64 or NULL  (row i = active row i, always)
  *   done_out  [n_active] u8           (row i = active row i, always)
  *   host_counts pinned host memory, 4 x int32, or NULL: receives
- *             {n_continue, n_stopped, sequence, reserved}.  Large batches: a
- *             copy issued on a side stream as soon as the stopping decisions
- *             are final -- before the state gather has run -- so that
- *             ttl_env_wait_counts() returns early and the host can queue the
- *             next step behind this one.  Batches of at most 16384 rows run
- *             prefix + compaction + gather as ONE kernel, which writes the
- *             counts and then a process-unique sequence number straight into
- *             this buffer (it must be device-visible pinned memory for that;
- *             otherwise the side-stream copy is used);
- *             ttl_env_wait_counts() polls the sequence word.
+ *             {n_continue, n_stopped, sequence, reserved}.  When the buffer is
+ *             device-visible (hipHostMalloc / torch pin_memory) the kernel
+ *             that computes the counts -- k_prefix, before the state gather
+ *             has even started, or the one-launch tail of batches of at most
+ *             16384 rows -- writes them and then a process-unique sequence
+ *             number straight into it, and ttl_env_wait_counts() polls that
+ *             word: the host can queue the next step while this one's gather
+ *             is still running, with no copy kernel competing for the CUs.
+ *             Otherwise (or with TTL_POLL_COUNTS=0) the counts are copied on
+ *             a side stream as soon as the stopping decisions are final.
  * Normalise + scale the action, first-step flip, grow by one point, LENGTH /
  * CURVATURE / MASK stopping tests, flags and dones, alignment reward, new
  * state.  continue_idx itself only changes in ttl_env_harvest(). */

@@ -385,6 +385,39 @@ def test_fused_and_three_launch_tails_agree_at_the_batch_boundaries(N, monkeypat
             assert np.array_equal(x, y, equal_nan=True), key
 
 
+@pytest.mark.parametrize('N', [3000, 20000])
+def test_count_delivery_paths_agree(N, monkeypatch):
+    """The survivor count written by the kernel into the pinned buffer and
+    polled (default) against the side-stream copy + event (TTL_POLL_COUNTS=0),
+    on the one-launch tail (N = 3000) and on the large-batch path (N = 20000)."""
+    D = 16
+    sh, mask, pk = synthetic_subject(D)
+    rng = np.random.RandomState(N)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    acts = [rng.standard_normal((N, 3)).astype(np.float32) for _ in range(6)]
+    runs = []
+    for poll in ('1', '0'):
+        monkeypatch.setenv('TTL_POLL_COUNTS', poll)
+        env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds, n_dirs=4,
+                       max_length=20.0, reward=False)
+        env.reset(0, N)
+        out = []
+        for step in range(6):
+            n = env._n_active
+            if n == 0:
+                break
+            _, _, done, _ = env.step_device(torch.from_numpy(acts[step][:n]).cuda())
+            state, _ = env.harvest()
+            assert env._n_active == int((done == 0).sum()) == state.shape[0]
+            assert int(env._host_counts_np[0]) + int(env._host_counts_np[1]) == n
+            out.append((env._n_active, env.continue_idx.copy()))
+        runs.append(out)
+    assert len(runs[0]) == len(runs[1]) > 2
+    for (na, ia), (nb, ib) in zip(*runs):
+        assert na == nb and np.array_equal(ia, ib)
+
+
 def _anisotropic_subject(shape, C=45, seed=77):
     """Non-cubic volumes: catches any x/y/z stride mix-up."""
     from tracktolearn_amd.datasets.utils import MRIDataVolume as Vol

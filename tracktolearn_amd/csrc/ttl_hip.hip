@@ -435,7 +435,8 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
                                                   int *__restrict__ idx_next,
                                                   const int *__restrict__ proc,
                                                   int n_active, int n_blocks,
-                                                  int order, int n_pts) {
+                                                  int order, int n_pts,
+                                                  int *__restrict__ host_word, int seq) {
     if (proc) {
         // first half of the processing-order compaction (slot order, same
         // grid): which slots survive, ranked inside their block
@@ -472,6 +473,15 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.counts[0] = total;
         P.counts[1] = n_active - total;
+        if (host_word) {
+            // straight into the caller's pinned buffer, sequence number last:
+            // the host polls it (ttl_env_wait_counts) and can queue the next
+            // step while the state gather of this one is still running
+            __hip_atomic_store(host_word + 0, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_word + 1, n_active - total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_word + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n_active) return;
@@ -798,6 +808,7 @@ struct ttl_env {
     int poll_seq;          // sequence number the polled word must reach
     hipStream_t poll_stream;
     int fuse_small;        // batches <= 16384 rows: one launch for prefix + gather
+    int poll_counts;       // counts written by the kernel into the pinned buffer (TTL_POLL_COUNTS)
     int local_sort;        // k_proc_scatter re-sorts each block's slots by current voxel
     int n_exact;           // n_active is the exact survivor count (read back)
     int prof_on;
@@ -1009,6 +1020,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     if (const char *v = getenv("TTL_FUSE_SMALL")) e->fuse_small = atoi(v);
     e->local_sort = 1;
     if (const char *v = getenv("TTL_LOCAL_SORT")) e->local_sort = atoi(v);
+    e->poll_counts = 1;
+    if (const char *v = getenv("TTL_POLL_COUNTS")) e->poll_counts = atoi(v);
     e->n_exact = 0;
     e->prof_mask = 7;
     e->prof_on = 0;
@@ -1219,54 +1232,54 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
     const int *proc = env->use_proc ? env->proc[env->proc_cur] : nullptr;
     env->stepped = 1;
     env->last_order = order;
+    // The survivor count goes straight into the caller's pinned buffer
+    // ({n_continue, n_stopped, sequence number}, written by the kernel that
+    // computes it) when that buffer is device-visible: no side stream, no copy
+    // kernel waiting for free CUs behind the gather, no API calls between the
+    // step's launches; the host polls the sequence word.
+    int *host_word = nullptr;
+    int seq = 0;
+    if (host_counts && env->poll_counts) {
+        if (env->host_probe != host_counts) {
+            void *dev = nullptr;
+            env->host_probe = host_counts;
+            env->host_dev = nullptr;
+            if (hipHostGetDevicePointer(&dev, host_counts, 0) == hipSuccess)
+                env->host_dev = static_cast<int *>(dev);
+            else
+                (void)hipGetLastError();      // not pinned: copy path below
+        }
+        host_word = env->host_dev;
+        static std::atomic<int> g_seq{1};
+        seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
+        if (seq == 0) seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
+    }
+    if (host_word) {
+        env->counts_pending = 2;
+        env->host_counts = host_counts;
+        env->poll_seq = seq;
+        env->poll_stream = s;
+    }
     if (!proc && env->fuse_small && env->state_kernel != 0 &&
         ttl_detail_can_fuse_tail(env->P, n_active)) {
-        // small batch: prefix + compaction + gather in ONE launch, and the
-        // survivor count written by that kernel straight into the caller's
-        // pinned buffer ({n_continue, n_stopped, sequence number}): no second
-        // launch, no side-stream copy, the host polls one word
-        int *host_word = nullptr;
-        int seq = 0;
-        if (host_counts) {
-            if (env->host_probe != host_counts) {
-                void *dev = nullptr;
-                env->host_probe = host_counts;
-                env->host_dev = nullptr;
-                if (hipHostGetDevicePointer(&dev, host_counts, 0) == hipSuccess)
-                    env->host_dev = static_cast<int *>(dev);
-                else
-                    (void)hipGetLastError();      // not pinned: copy path below
-            }
-            host_word = env->host_dev;
-            static std::atomic<int> g_seq{1};
-            seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
-            if (seq == 0) seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
-        }
+        // small batch: prefix + compaction + gather in ONE launch
         prof_mark(env, 2, 0, s);
         const int rc = ttl_detail_launch_fused_tail(env->P, idx, idx_next, n_active, order,
                                                     n_pts, state_out, state_pitch,
                                                     host_word, seq, s);
         prof_mark(env, 2, 1, s);
         if (rc != TTL_OK) return rc;
-        if (host_counts && host_word) {
-            env->counts_pending = 2;
-            env->host_counts = host_counts;
-            env->poll_seq = seq;
-            env->poll_stream = s;
-        } else if (host_counts) {
-            HIP_TRY(ttl_copy_counts(env, host_counts, s));
-        }
+        if (host_counts && !host_word) HIP_TRY(ttl_copy_counts(env, host_counts, s));
         return TTL_OK;
     }
     prof_mark(env, 1, 0, s);
     hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
-                       proc, n_active, nb, order, n_pts);
+                       proc, n_active, nb, order, n_pts, host_word, seq);
     prof_mark(env, 1, 1, s);
     HIP_TRY(hipGetLastError());
-    if (host_counts) {
-        // the survivor count is final once k_prefix has run: ship it to the
-        // host on a side stream now, so the host can queue the next step
-        // while k_state is still running
+    if (host_counts && !host_word) {
+        // fallback (buffer not device-visible): ship the count on a side stream
+        // as soon as k_prefix has run
         HIP_TRY(ttl_copy_counts(env, host_counts, s));
     }
     if (proc) {
