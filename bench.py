@@ -18,6 +18,8 @@ window bracketed by barrier + torch.cuda.synchronize() on both sides and
 started from a fresh (untimed) reset, so all windows time the same K steps.
 `value` / `ms_per_step` are those of the MEDIAN window (max over ranks per
 window); min / max over the windows are printed next to them (`windows`).
+Every second window also brackets the dominant kernel with HIP events (for
+`roofline`); those records cost a few percent, both medians are printed.
 One 12-step window is ~3 ms of GPU time, which is why one window alone is a
 fragile figure.
 
@@ -335,11 +337,18 @@ def main(argv=None):
     torch.cuda.synchronize()
 
     # ---- timed windows: each EXACTLY --steps steps from a fresh reset ------
+    # The dominant kernel is bracketed with HIP events in every second window
+    # only: an event record costs ~6 us of GPU idle time on either side of the
+    # kernel (rocprofv3 trace, benchmarks/trace_gaps.py), ~5 % of a step.  All
+    # windows are timed alike and `value` is the median over all of them.
     n_win = max(1, args.windows)
-    env.profile_begin(max_launches=n_win * (args.steps + 2) + 8, classes=('state',))
     times, n_units, resets = [], 0, 0
-    for _ in range(n_win):
+    state_ms, state_n, evented = 0.0, 0, []
+    for w in range(n_win):
         counter = {'state': env.reset(0, N_ACTOR), 'step': 0, 'resets': 0}
+        with_events = (w % 2 == 1) or n_win == 1
+        if with_events:
+            env.profile_begin(max_launches=args.steps + 8, classes=('state',))
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -348,7 +357,11 @@ def main(argv=None):
         barrier()
         times.append(time.perf_counter() - t0)
         resets = max(resets, counter['resets'])
-    prof = env.profile_end()
+        if with_events:
+            ms, cnt = env.profile_end()['state']
+            state_ms += ms
+            state_n += cnt
+            evented.append(w)
 
     # untimed replay of the same steps with every kernel class bracketed, for
     # the per-kernel breakdown (the timed windows only bracket the dominant
@@ -409,13 +422,13 @@ def main(argv=None):
     if world > 1:
         dist.all_reduce(t_win, op=dist.ReduceOp.MAX)      # per window, over ranks
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
-    t_win = np.sort(t_win.cpu().numpy())
+    t_all = t_win.cpu().numpy()          # per window, max over the ranks
+    t_win = np.sort(t_all)
     total_units = float(units.item())        # of ONE window, all ranks
     t_med = float(t_win[len(t_win) // 2])
 
     if rank == 0:
         whole_b, kern_b = algorithmic_bytes(C, N_DIRS)
-        state_ms, state_n = prof['state']
         adv_ms, adv_n = prof_all['advance']
         pre_ms, _ = prof_all['prefix']
         avg_launch_s = state_ms / max(state_n, 1) * 1e-3
@@ -468,6 +481,12 @@ def main(argv=None):
             'windows': {
                 'n': len(t_win), 'timed': 'each window = exactly --steps steps '
                 'from a fresh untimed reset; value/ms_per_step = median window',
+                'with_kernel_events': evented,
+                'value_median_with_events': (total_units / float(np.median(
+                    [t_all[i] for i in evented]))) if evented else None,
+                'value_median_without_events': (total_units / float(np.median(
+                    [t_all[i] for i in range(len(t_all)) if i not in evented])))
+                if len(evented) < len(t_all) else None,
                 'value_min': total_units / float(t_win[-1]),
                 'value_median': value,
                 'value_max': total_units / float(t_win[0]),
