@@ -30,6 +30,39 @@ def main():
     for s, e, n, g in rows:
         if n.startswith('k_'):
             durs.setdefault(n, []).append(e - s)
+    # GPU busy fraction over runs of kernels separated by less than 1 ms
+    busy, span, start, last_end = 0, 0, None, None
+    for s0, e0, n, g in rows:
+        if not n.startswith('k_'):
+            continue
+        if last_end is None or s0 - last_end > 1_000_000:
+            if start is not None:
+                span += last_end - start
+            start = s0
+        busy += e0 - s0
+        last_end = max(last_end or 0, e0)
+    if start is not None:
+        span += last_end - start
+    print(f'kernels busy {busy / 1e6:.2f} ms of {span / 1e6:.2f} ms spanned ({100.0 * busy / max(span, 1):.1f} %)')
+    # the same per size class of the step (rows of its k_advance launch)
+    classes = {}
+    cur = None
+    for s0, e0, n, g in rows:
+        if n == 'k_scripted_actions':
+            cur = [g, s0, 0, e0]
+            classes.setdefault('tmp', []).append(cur)
+        if cur is not None and n.startswith('k_'):
+            cur[2] += e0 - s0
+            cur[3] = max(cur[3], e0)
+    steps = classes.get('tmp', [])
+    for lo, hi in ((131072, 1 << 30), (65536, 131072), (16384, 65536), (4096, 16384), (0, 4096)):
+        sel = [(st_[2], nx[1] - st_[1]) for st_, nx in zip(steps, steps[1:])
+               if lo <= st_[0] < hi and nx[1] - st_[1] < 1_000_000]
+        if sel:
+            b = sum(x for x, _ in sel)
+            w = sum(y for _, y in sel)
+            print(f'  steps of [{lo}, {hi}) rows: {len(sel)} steps, kernels busy {100.0 * b / w:.1f} % '
+                  f'of the step-to-step time, {w / len(sel) / 1e3:.1f} us per step')
     print('kernel durations (ns): median over all launches')
     for n, v in sorted(durs.items()):
         print(f'  {n:24s} n={len(v):4d} median {st.median(v):9.0f}')
