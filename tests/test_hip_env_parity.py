@@ -605,6 +605,41 @@ def test_error_paths_return_codes_not_faults():
     env.harvest()
 
 
+def test_counts_into_pageable_host_memory_fall_back_to_the_copy():
+    """`host_counts` that is NOT pinned / device-visible (a plain numpy
+    buffer): the library notices (hipHostGetDevicePointer fails), keeps the
+    kernel from writing through it and delivers the counts with the side-stream
+    copy instead; same numbers as through the pinned, polled buffer."""
+    D, N = 12, 300
+    sh, mask, pk = synthetic_subject(D)
+    rng = np.random.RandomState(4)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds, n_dirs=4,
+                   max_length=10.0, reward=False)
+    env.reset(0, N)
+    lib, h, W = env._lib, env._handle, env._state_width
+    stream = env._stream()
+    acts = torch.randn(N, 3, device='cuda')
+    state = torch.empty((N, W), dtype=torch.float32, device='cuda')
+    done = torch.empty(N, dtype=torch.uint8, device='cuda')
+    pageable = np.full(4, -7, dtype=np.int32)
+    assert lib.ttl_env_step(h, acts.data_ptr(), None, N, 1, state.data_ptr(), W, None,
+                            done.data_ptr(), pageable.ctypes.data, stream) == 0
+    assert lib.ttl_env_harvest(h, None, None, W, stream) == 0
+    assert lib.ttl_env_wait_counts(h) == 0
+    n_stopped = int(done.sum())
+    assert pageable[0] == N - n_stopped and pageable[1] == n_stopped
+    assert pageable[2] == -7                     # no sequence word on this path
+    # the next step must be launched for exactly the survivors
+    n = int(pageable[0])
+    assert lib.ttl_env_step(h, acts.data_ptr(), None, n + 1, 1, state.data_ptr(), W, None,
+                            done.data_ptr(), pageable.ctypes.data, stream) == -1
+    assert lib.ttl_env_step(h, acts.data_ptr(), None, n, 1, state.data_ptr(), W, None,
+                            done.data_ptr(), pageable.ctypes.data, stream) == 0
+    torch.cuda.synchronize()
+
+
 def test_episode_on_a_non_default_stream():
     """Everything is ordered on the caller's stream (torch's current stream):
     a whole device-resident episode of 20 000 streamlines issued inside a
