@@ -234,6 +234,14 @@ int ttl_env_wait_counts(ttl_env *env);
 int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
                     int64_t state_pitch, void *hip_stream);
 
+/* ttl_env_harvest() followed by ttl_env_wait_counts() in one call (one trip
+ * through the FFI instead of two; small batches are host bound): returns the
+ * survivor count through n_continue_out.  The last step must have been given
+ * host_counts. */
+int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
+                         int64_t state_pitch, void *hip_stream,
+                         int32_t *n_continue_out);
+
 /* BaseEnv._compute_stopping_flags (env.py:567-603) on caller-supplied points:
  * tail [n][3][3] f32 holds the last three points (oldest first) of n
  * streamlines that have n_points points each (with n_points == 2 the first

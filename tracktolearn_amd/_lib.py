@@ -91,6 +91,8 @@ SYMBOLS = {
                                    C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p]),
     'ttl_env_wait_counts': (C.c_int, [C.c_void_p]),
+    'ttl_env_harvest_wait': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.POINTER(C.c_int32)]),
     'ttl_env_harvest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
     'ttl_env_stopping_flags': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,

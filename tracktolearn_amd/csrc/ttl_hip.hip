@@ -1390,6 +1390,17 @@ int ttl_env_wait_counts(ttl_env *env) {
     return TTL_OK;
 }
 
+int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
+                         int64_t state_pitch, void *hip_stream, int32_t *n_continue_out) {
+    if (!n_continue_out) return fail(TTL_ERR_INVALID, "ttl_env_harvest_wait: null argument");
+    int rc = ttl_env_harvest(env, state_in, state_out, state_pitch, hip_stream);
+    if (rc != TTL_OK) return rc;
+    rc = ttl_env_wait_counts(env);
+    if (rc != TTL_OK) return rc;
+    *n_continue_out = env->n_active;
+    return TTL_OK;
+}
+
 int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
                            int32_t n_points, uint8_t *flags_out,
                            void *hip_stream) {

@@ -289,15 +289,15 @@ class TrackingEnvironment(BaseEnv):
         out = None
         if order == _lib.ORDER_ACTIVE:
             out = self._new_state(state_in.shape[0])
-        _lib.check(self._lib.ttl_env_harvest(
+        # the survivor count left the GPU right after the stopping decisions
+        # (written by the step's kernel into pinned memory): this wait does not
+        # cover the state gather
+        n_out = self._n_continue_out
+        _lib.check(self._lib.ttl_env_harvest_wait(
             self._handle, state_in.data_ptr(),
             out.data_ptr() if out is not None else None, self._state_pitch,
-            self._stream()), 'ttl_env_harvest')
-        # the survivor count left the GPU right after the stopping decisions
-        # (side stream): this wait does not cover the state gather
-        _lib.check(self._lib.ttl_env_wait_counts(self._handle),
-                   'ttl_env_wait_counts')
-        n_cont = int(self._host_counts_np[0])
+            self._stream(), n_out), 'ttl_env_harvest')
+        n_cont = n_out.value
         if order == _lib.ORDER_ACTIVE:
             new_state = out[:n_cont]
         else:
