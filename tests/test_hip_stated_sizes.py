@@ -526,3 +526,31 @@ def test_reference_learner_vectors_on_the_gpu(name, monkeypatch):
         assert np.allclose(det.cpu().numpy(), z['act_det'], atol=GOLDEN_TOL)
         assert np.allclose(a.cpu().numpy(), z['act_sto'], atol=GOLDEN_TOL)
         assert np.allclose(logp.cpu().numpy(), z['act_sto_logp'], atol=1e-4)
+
+
+def test_reference_replay_ring_vectors_on_the_gpu():
+    """tests/golden/learner_replay.npz (the reference's OffPolicyReplayBuffer:
+    `ptr`, `size` and ring contents after adds that wrap around) replayed by the
+    HBM-resident ring on cuda:0, through `add` and through the partition-order
+    entry point the device loops use."""
+    from helpers import load_trace
+    from tracktolearn_amd.algorithms.shared.replay import OffPolicyReplayBuffer
+    z = load_trace('learner_replay')
+    dev = torch.device(DEV)
+    buf = OffPolicyReplayBuffer(5, 3, max_size=10, device=dev)
+    twin = OffPolicyReplayBuffer(5, 3, max_size=10, device=dev)
+    rng = np.random.RandomState(0)
+    for i in range(int(z['n_adds'])):
+        args = [torch.from_numpy(z[f'add{i}/{k}']).to(dev) for k in ('s', 'a', 'ns', 'r', 'd')]
+        buf.add(*args)
+        n = len(args[0])
+        dest = torch.from_numpy(rng.permutation(n)).to(dev)
+        ns_part = torch.empty_like(args[2])
+        ns_part[dest] = args[2]
+        twin.add_partitioned(args[0], args[1], ns_part, dest, args[3], args[4])
+        for b in (buf, twin):
+            assert b.ptr == int(z[f'after{i}/ptr']) and b.size == int(z[f'after{i}/size'])
+            for name in ('state', 'action', 'next_state', 'reward', 'not_done'):
+                assert np.array_equal(getattr(b, name).cpu().numpy(), z[f'after{i}/{name}'])
+    s, a, ns, r, d = buf.sample(4)
+    assert s.is_cuda and s.shape == (4, 5) and r.shape == (4,)
