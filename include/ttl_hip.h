@@ -33,12 +33,13 @@
 extern "C" {
 #endif
 
-#define TTL_ABI_VERSION 6
+#define TTL_ABI_VERSION 7
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
 #define TTL_ERR_HIP (-2)     /* a HIP runtime call failed                    */
 #define TTL_ERR_STATE (-3)   /* call order violated (e.g. step before reset) */
+#define TTL_ERR_UNSUPPORTED (-4) /* the configuration has no such path (free-running steps) */
 
 /* Direction arithmetic, TTL/environments/env.py:493-502:
  *   F32      normalise, scale and add in float32 (training env, float32
@@ -241,6 +242,40 @@ int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
 int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
                          int64_t state_pitch, void *hip_stream,
                          int32_t *n_continue_out);
+
+/* Free-running steps (ABI v7).  The tracking loops of the reference
+ * (RLAlgorithm.validation_episode, rl.py:58-106, driven by Tracker.track,
+ * tracker.py:110-116) run policy -> step -> harvest until every streamline of
+ * the batch has stopped; with the default --n_actor (10 000) a step is a few
+ * microseconds of GPU work and the loop is bound by the host's launches and by
+ * the survivor count it fetches every step.  Between ttl_env_freerun_begin()
+ * and ttl_env_freerun_end() the number of active rows, the current length and
+ * the live continue_idx buffer are kept in device memory and advanced by the
+ * step's own kernels, so ttl_env_freerun_step() is nothing but launches with
+ * fixed arguments: it may be captured in a HIP graph (together with the policy
+ * network that turns state rows into actions) and replayed until the pinned
+ * words report no survivor.  Results are those of ttl_env_step(ORDER_PARTITION)
+ * + ttl_env_harvest() on the same actions, row for row.
+ *
+ * begin: after a reset or a harvested step whose count was read; batches of at
+ *   most 16 384 rows (TTL_ERR_UNSUPPORTED otherwise, also for a neighbourhood
+ *   radius outside (0, 1) voxel).  host_counts (may be NULL): 4 int32 of
+ *   pinned, device-visible memory; every step writes {n_continue, n_stopped,
+ *   steps done since begin} there.
+ * step: actions [n][3] f32, state_out [n][state_pitch] f32, reward_out [n] f64
+ *   or NULL, done_out [n] u8 -- all for the n rows active at begin.  Rows
+ *   0..n_active-1 (n_active as the previous step left it) are the active rows;
+ *   state rows come out survivors first (stable), then the rows that stopped
+ *   in this step; rows that left earlier get done = 1, reward = 0 and keep
+ *   their old state row.  No Gaussian action noise (TTL_MODE_F64DIR adds +0.0).
+ * end: waits for the stream, reads the device words back into the handle
+ *   (which then continues as after a harvest) and returns them. */
+int ttl_env_freerun_begin(ttl_env *env, int32_t *host_counts, void *hip_stream);
+int ttl_env_freerun_step(ttl_env *env, const float *actions, float *state_out,
+                         int64_t state_pitch, double *reward_out, uint8_t *done_out,
+                         void *hip_stream);
+int ttl_env_freerun_end(ttl_env *env, int32_t *n_active_out, int32_t *length_out,
+                        int32_t *steps_out, void *hip_stream);
 
 /* BaseEnv._compute_stopping_flags (env.py:567-603) on caller-supplied points:
  * tail [n][3][3] f32 holds the last three points (oldest first) of n

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (keep above the CDLL below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 SH_LINEAR, SH_BRICK4 = 0, 1
 MODE_F32 = 0
 MODE_F64DIR = 1
@@ -26,6 +26,7 @@ MODE_F32NORM = 2
 ORDER_ACTIVE = 0
 ORDER_PARTITION = 1
 ORDER_BY_POSITION = C.c_void_p(1)      # TTL_ORDER_BY_POSITION (ttl_env_reset)
+ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = -1, -2, -3, -4
 
 
 class TTLError(RuntimeError):
@@ -95,6 +96,12 @@ SYMBOLS = {
                                        C.c_void_p, C.POINTER(C.c_int32)]),
     'ttl_env_harvest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
+    'ttl_env_freerun_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttl_env_freerun_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttl_env_freerun_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.c_void_p]),
     'ttl_env_stopping_flags': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p]),
     'ttl_env_set_processing_order': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32,

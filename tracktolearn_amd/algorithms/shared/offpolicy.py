@@ -61,6 +61,21 @@ class MaxEntropyActor(Actor):
         logp = logp - (2 * (np.log(2) - u - F.softplus(-2 * u))).sum(axis=1)
         return self.output_activation(u), logp
 
+    def sample(self, state, probabilistic):
+        """The action of ``forward`` without its log-probability (tracking and
+        sample gathering only use the action, offpolicy.py:467-482): the same
+        ``tanh(mu + eps * std)``, bit for bit, in 9 launches instead of ~35 --
+        with the default networks a tracking step is bound by exactly those
+        launches.  ``probabilistic == 0`` gives ``tanh(mu)`` (``eps * 0`` adds
+        nothing) and draws no random numbers."""
+        p = self.layers(state)
+        mu = p[:, :self.action_dim]
+        if not probabilistic:
+            return self.output_activation(mu)
+        log_std = torch.clamp(p[:, self.action_dim:], LOG_STD_MIN, LOG_STD_MAX)
+        std = torch.exp(log_std) * probabilistic
+        return self.output_activation(mu + torch.randn_like(mu) * std)
+
 
 class Critic(nn.Module):
     """Q(s, a) (offpolicy.py:143-181)."""
@@ -97,6 +112,9 @@ class ActorCritic(object):
 
     actor_cls = Actor
     critic_cls = Critic
+    #: select_action is plain torch code without a host round trip: it can run
+    #: under stream capture (RLAlgorithm.validation_episode's graphed loop)
+    graph_safe = True
 
     def __init__(self, state_dim, action_dim, hidden_dims, device):
         self.device = device
@@ -159,5 +177,4 @@ class SACActorCritic(ActorCritic):
     def select_action(self, state, probabilistic=1.0):
         if len(state.shape) < 2:
             state = state[None, :]
-        action, _ = self.act(state, probabilistic)
-        return action
+        return self.actor.sample(state, probabilistic)

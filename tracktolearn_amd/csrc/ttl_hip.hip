@@ -250,16 +250,16 @@ __device__ __forceinline__ void block_survivor_ranks(const EnvParams &P, int i,
 // ---------------------------------------------------------------------------
 // k_advance: one thread per active streamline.
 // ---------------------------------------------------------------------------
+// One active row of a step: streamline g = idx[i] grows by one point, the
+// stopping criteria are tested on it, reward / done / head records are written.
+// Returns whether the streamline stops.
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_advance(
-    EnvParams P, const int *__restrict__ idx, const float *__restrict__ actions,
-    const double *__restrict__ noise, int n_active, int L,
-    double *__restrict__ reward_out, uint8_t *__restrict__ done_out) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    const bool active = i < n_active;
+__device__ __forceinline__ bool advance_row(
+    const EnvParams &P, int g, int i, const float *__restrict__ actions,
+    const double *__restrict__ noise, int L, double *__restrict__ reward_out,
+    uint8_t *__restrict__ done_out) {
     bool stop = false;
-    if (active) {
-        const int g = idx[i];
+    {
         float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
         // the two newest points come from a compact per-streamline array (32 B
         // each, walked in ascending id order = nearly sequentially), not from
@@ -393,8 +393,69 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
         *reinterpret_cast<float4 *>(P.head + 4 * (size_t)i) =
             float4{p2x, p2y, p2z, __int_as_float(g)};
     }
+    return stop;
+}
 
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_advance(
+    EnvParams P, const int *__restrict__ idx, const float *__restrict__ actions,
+    const double *__restrict__ noise, int n_active, int L,
+    double *__restrict__ reward_out, uint8_t *__restrict__ done_out) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < n_active;
+    bool stop = false;
+    if (active)
+        stop = advance_row<MODE>(P, idx[i], i, actions, noise, L, reward_out, done_out);
     block_survivor_ranks(P, i, active, active && !stop);
+}
+
+// ---------------------------------------------------------------------------
+// Free-running step (ttl_env_freerun_*): the number of active rows, the
+// current length and which of the two continue_idx buffers is live come from
+// device memory, so that a step is a fixed sequence of launches that can be
+// captured in a HIP graph and replayed without the host in the loop.
+// P.counts + TTL_FR_LIVE  = {n_active, length, cur, steps done}: read by
+// k_advance_fr, rewritten by the step's last kernel (k_prefix_state_fr);
+// P.counts + TTL_FR_SNAP  = the same four words as this step found them:
+// written by k_advance_fr, read by k_prefix_state_fr.
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_advance_fr(
+    EnvParams P, const int *__restrict__ idx_a, const int *__restrict__ idx_b,
+    const float *__restrict__ actions, int n_cap, double *__restrict__ reward_out,
+    uint8_t *__restrict__ done_out) {
+    const int *live = P.counts + TTL_FR_LIVE;
+    int n_active = live[0];
+    const int L = live[1], cur = live[2];
+    // a full history takes no more points (cannot happen while rows are
+    // active: the LENGTH criterion has stopped them; guards the history write)
+    if (L < 1 || L > P.max_nb_steps || n_active > n_cap) n_active = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int *snap = P.counts + TTL_FR_SNAP;
+        snap[0] = n_active;
+        snap[1] = L;
+        snap[2] = cur;
+        snap[3] = live[3];
+    }
+    const int *idx = cur ? idx_b : idx_a;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = i < n_active;
+    bool stop = false;
+    if (active) {
+        stop = advance_row<MODE>(P, idx[i], i, actions, nullptr, L, reward_out, done_out);
+    } else if (i < n_cap) {      // rows that left the episode earlier
+        done_out[i] = 1;
+        if (reward_out) reward_out[i] = 0.0;
+    }
+    block_survivor_ranks(P, i, active, active && !stop);
+}
+
+__global__ void k_fr_init(EnvParams P, int n_active, int length, int cur) {
+    int *live = P.counts + TTL_FR_LIVE;
+    live[0] = n_active;
+    live[1] = length;
+    live[2] = cur;
+    live[3] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -811,6 +872,8 @@ struct ttl_env {
     int poll_counts;       // counts written by the kernel into the pinned buffer (TTL_POLL_COUNTS)
     int local_sort;        // k_proc_scatter re-sorts each block's slots by current voxel
     int n_exact;           // n_active is the exact survivor count (read back)
+    int fr_cap;            // > 0: free-running steps are being enqueued for this many rows
+    int *fr_host_word;     // device address of the pinned words a free-running step reports to
     int prof_on;
     int prof_mask;    // bit k: time kernel class k
     int prof_cap;     // event pairs available per kernel class
@@ -1023,6 +1086,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->poll_counts = 1;
     if (const char *v = getenv("TTL_POLL_COUNTS")) e->poll_counts = atoi(v);
     e->n_exact = 0;
+    e->fr_cap = 0;
+    e->fr_host_word = nullptr;
     e->prof_mask = 7;
     e->prof_on = 0;
     e->prof_cap = 0;
@@ -1127,6 +1192,7 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
     env->n_active = n;
     env->n_exact = 1;
     env->stepped = 0;
+    env->fr_cap = 0;
     env->proc_cur = 0;
     env->use_proc = processing_order != nullptr;
     if (processing_order == TTL_ORDER_BY_POSITION) {
@@ -1168,6 +1234,7 @@ int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
     if (!env || !actions || !done_out)
         return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
     if (env->length < 1) return fail(TTL_ERR_STATE, "ttl_env_step: reset first");
+    if (env->fr_cap) return fail(TTL_ERR_STATE, "ttl_env_step: free-running steps are enqueued, call ttl_env_freerun_end first");
     if (env->stepped) return fail(TTL_ERR_STATE, "ttl_env_step: harvest the previous step first");
     if (n_active < 1 || n_active > env->n_active ||
         (env->n_exact && n_active != env->n_active))
@@ -1398,6 +1465,91 @@ int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
     rc = ttl_env_wait_counts(env);
     if (rc != TTL_OK) return rc;
     *n_continue_out = env->n_active;
+    return TTL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Free-running steps: a step as a fixed sequence of launches whose row count,
+// length and buffer parity live in device memory, for capture in a HIP graph.
+// ---------------------------------------------------------------------------
+int ttl_env_freerun_begin(ttl_env *env, int32_t *host_counts, void *hip_stream) {
+    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_freerun_begin: null handle");
+    if (env->length < 1) return fail(TTL_ERR_STATE, "ttl_env_freerun_begin: reset first");
+    if (env->stepped) return fail(TTL_ERR_STATE, "ttl_env_freerun_begin: harvest the previous step first");
+    if (env->fr_cap) return fail(TTL_ERR_STATE, "ttl_env_freerun_begin: already free-running");
+    if (!env->n_exact)
+        return fail(TTL_ERR_STATE, "ttl_env_freerun_begin: the survivor count of the last step has not been read");
+    if (env->n_active < 1) return fail(TTL_ERR_STATE, "ttl_env_freerun_begin: no active streamline");
+    if (env->state_kernel == 0 || !ttl_detail_can_fuse_tail(env->P, env->n_active))
+        return fail(TTL_ERR_UNSUPPORTED, "ttl_env_freerun_begin: needs a batch of at most %d rows, "
+                    "a neighbourhood radius in (0, 1) voxel and a volume below 4 GiB", 64 * BLOCK);
+    hipStream_t s = (hipStream_t)hip_stream;
+    env->fr_host_word = nullptr;
+    if (host_counts) {
+        void *dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, host_counts, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TTL_ERR_INVALID, "ttl_env_freerun_begin: host_counts must be pinned, device-visible memory");
+        }
+        env->fr_host_word = static_cast<int *>(dev);
+        host_counts[0] = env->n_active;
+        host_counts[1] = 0;
+        host_counts[2] = 0;
+    }
+    hipLaunchKernelGGL(k_fr_init, dim3(1), dim3(1), 0, s, env->P, env->n_active, env->length,
+                       env->cur);
+    HIP_TRY(hipGetLastError());
+    env->use_proc = 0;
+    env->counts_pending = 0;
+    env->fr_cap = env->n_active;
+    return TTL_OK;
+}
+
+int ttl_env_freerun_step(ttl_env *env, const float *actions, float *state_out,
+                         int64_t state_pitch, double *reward_out, uint8_t *done_out,
+                         void *hip_stream) {
+    if (!env || !actions || !state_out || !done_out)
+        return fail(TTL_ERR_INVALID, "ttl_env_freerun_step: null argument");
+    if (!env->fr_cap) return fail(TTL_ERR_STATE, "ttl_env_freerun_step: call ttl_env_freerun_begin first");
+    const ttl_env_desc &d = env->d;
+    const int64_t width = 7LL * d.n_coef + 3LL * d.n_dirs;
+    if (state_pitch < width)
+        return fail(TTL_ERR_INVALID, "ttl_env_freerun_step: state_pitch too small");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int n_cap = env->fr_cap;
+    const int nb = (n_cap + BLOCK - 1) / BLOCK;
+    // launches only: nothing below waits, copies or asks the runtime anything,
+    // so the call may run under stream capture
+#define TTL_LAUNCH_ADVANCE_FR(M)                                                     \
+    hipLaunchKernelGGL((k_advance_fr<M>), dim3(nb), dim3(BLOCK), 0, s, env->P, d.idx_a, \
+                       d.idx_b, actions, n_cap, reward_out, done_out)
+    if (d.mode == TTL_MODE_F32) TTL_LAUNCH_ADVANCE_FR(TTL_MODE_F32);
+    else if (d.mode == TTL_MODE_F64DIR) TTL_LAUNCH_ADVANCE_FR(TTL_MODE_F64DIR);
+    else TTL_LAUNCH_ADVANCE_FR(TTL_MODE_F32NORM);
+#undef TTL_LAUNCH_ADVANCE_FR
+    HIP_TRY(hipGetLastError());
+    return ttl_detail_launch_fused_tail_fr(env->P, d.idx_a, d.idx_b, n_cap, state_out,
+                                           state_pitch, env->fr_host_word, s);
+}
+
+int ttl_env_freerun_end(ttl_env *env, int32_t *n_active_out, int32_t *length_out,
+                        int32_t *steps_out, void *hip_stream) {
+    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_freerun_end: null handle");
+    if (!env->fr_cap) return fail(TTL_ERR_STATE, "ttl_env_freerun_end: not free-running");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int live[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(live, env->P.counts + TTL_FR_LIVE, sizeof(live),
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    env->n_active = live[0];
+    env->n_exact = 1;
+    env->length = live[1];
+    env->cur = live[2];
+    env->stepped = 0;
+    env->fr_cap = 0;
+    if (n_active_out) *n_active_out = live[0];
+    if (length_out) *length_out = live[1];
+    if (steps_out) *steps_out = live[3];
     return TTL_OK;
 }
 

@@ -67,8 +67,14 @@ struct EnvParams {
     int slot_rec;      // the gather reads the slot records (0: resolves proc -> idx/row_dest/head itself)
     int store_flavour; // cache policy of the state-row stores (TTL_STORE_FLAVOUR, see store16)
     int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
-    int *counts;       // {n_continue, n_stopped}
+    int *counts;       // {n_continue, n_stopped}; 64 ints: the free-running step's words live here too
 };
+
+// free-running step (ttl_env_freerun_*): int offsets into EnvParams::counts of
+// {n_active, length, cur, steps done} -- live (between steps) and the snapshot
+// a step works from
+constexpr int TTL_FR_LIVE = 8;
+constexpr int TTL_FR_SNAP = 16;
 
 // Record index of voxel (x, y, z) = vox_x(x) + vox_y(y) + vox_z(z), for both
 // record orders (separable, so the gather keeps per-axis partial offsets).
@@ -103,6 +109,13 @@ bool ttl_detail_can_fuse_tail(const EnvParams &P, int n_active);
 int ttl_detail_launch_fused_tail(const EnvParams &P, const int *idx, int *idx_next,
                                  int n_active, int order, int n_pts, float *out,
                                  int64_t pitch, int *host_word, int seq, hipStream_t s);
+// ttl_state.hip: the same tail for a free-running step: n_active, the length
+// and the live continue_idx buffer are read from P.counts + TTL_FR_SNAP, the
+// next step's words are written to P.counts + TTL_FR_LIVE; rows in partition
+// order; n_cap = rows the launch covers
+int ttl_detail_launch_fused_tail_fr(const EnvParams &P, int *idx_a, int *idx_b, int n_cap,
+                                    float *out, int64_t pitch, int *host_word,
+                                    hipStream_t s);
 // ttl_order.hip: rows 0..n-1 sorted by the 8^3-voxel brick of their newest
 // point (P.last2 of streamline idx[row]) -> order_out[n]; ws = scratch of
 // ttl_detail_order_workspace_bytes(n_max) bytes

@@ -459,11 +459,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
 // step's sequence number -- the host polls that word instead of waiting for a
 // copy on a side stream.
 // ---------------------------------------------------------------------------
-template <int LPS, bool MERGE_TAIL>
-__global__ __launch_bounds__(BLOCK, 4) void k_prefix_state(
-    EnvParams P, const int *__restrict__ idx, int *__restrict__ idx_next, int n_active,
+template <int LPS, bool MERGE_TAIL, bool FR>
+__device__ __forceinline__ void prefix_state_body(
+    const EnvParams &P, const int *__restrict__ idx, int *__restrict__ idx_next, int n_active,
     int n_blocks, int order, int n_pts, float *__restrict__ out, long long pitch,
-    int *__restrict__ host_word, int seq) {
+    int *__restrict__ host_word, int seq, int cur) {
     constexpr int GPW = 64 / LPS;
     constexpr int ROWS = (BLOCK / 64) * GPW;
     __shared__ int s_before[65];
@@ -484,6 +484,15 @@ __global__ __launch_bounds__(BLOCK, 4) void k_prefix_state(
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.counts[0] = total;
         P.counts[1] = n_active - total;
+        if (FR) {
+            // the next step's words; a step without active rows changes nothing
+            // but the step counter
+            int *live = P.counts + TTL_FR_LIVE;
+            live[0] = total;
+            live[1] = n_active > 0 ? n_pts : n_pts - 1;
+            live[2] = n_active > 0 ? cur ^ 1 : cur;
+            live[3] = seq;
+        }
         if (host_word) {
             __hip_atomic_store(host_word + 0, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(host_word + 1, n_active - total, __ATOMIC_RELAXED,
@@ -510,6 +519,28 @@ __global__ __launch_bounds__(BLOCK, 4) void k_prefix_state(
     const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
     state_row_dd<LPS, false, MERGE_TAIL>(P, hp.x, hp.y, hp.z, h, n_pts, sub,
                                          out + (size_t)dest * (size_t)pitch);
+}
+
+template <int LPS, bool MERGE_TAIL>
+__global__ __launch_bounds__(BLOCK, 4) void k_prefix_state(
+    EnvParams P, const int *__restrict__ idx, int *__restrict__ idx_next, int n_active,
+    int n_blocks, int order, int n_pts, float *__restrict__ out, long long pitch,
+    int *__restrict__ host_word, int seq) {
+    prefix_state_body<LPS, MERGE_TAIL, false>(P, idx, idx_next, n_active, n_blocks, order,
+                                              n_pts, out, pitch, host_word, seq, 0);
+}
+
+// the tail of a free-running step (see k_advance_fr): everything that changes
+// from step to step is read from the snapshot k_advance_fr left
+template <int LPS, bool MERGE_TAIL>
+__global__ __launch_bounds__(BLOCK, 4) void k_prefix_state_fr(
+    EnvParams P, int *__restrict__ idx_a, int *__restrict__ idx_b, int n_blocks,
+    float *__restrict__ out, long long pitch, int *__restrict__ host_word) {
+    const int *snap = P.counts + TTL_FR_SNAP;
+    const int n_active = snap[0], L = snap[1], cur = snap[2], seq = snap[3] + 1;
+    prefix_state_body<LPS, MERGE_TAIL, true>(P, cur ? idx_b : idx_a, cur ? idx_a : idx_b,
+                                             n_active, n_blocks, TTL_ORDER_PARTITION, L + 1,
+                                             out, pitch, host_word, seq, cur);
 }
 
 }  // namespace
@@ -542,6 +573,27 @@ int ttl_detail_launch_fused_tail(const EnvParams &P, const int *idx, int *idx_ne
     else if (C4 <= 12) TTL_LAUNCH_FUSED(12);
     else TTL_LAUNCH_FUSED(16);
 #undef TTL_LAUNCH_FUSED
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
+}
+
+int ttl_detail_launch_fused_tail_fr(const EnvParams &P, int *idx_a, int *idx_b, int n_cap,
+                                    float *out, int64_t pitch, int *host_word,
+                                    hipStream_t s) {
+    const int C4 = P.coef_pitch >> 2;
+    const int n_blocks = (n_cap + BLOCK - 1) / BLOCK;
+#define TTL_LAUNCH_FUSED_FR(LPS)                                                     \
+    do {                                                                             \
+        const int rows_per_block = (BLOCK / 64) * (64 / LPS);                        \
+        const dim3 grid((n_cap + rows_per_block - 1) / rows_per_block);              \
+        hipLaunchKernelGGL((k_prefix_state_fr<LPS, true>), grid, dim3(BLOCK), 0, s, P, idx_a, \
+                           idx_b, n_blocks, out, (long long)pitch, host_word);       \
+    } while (0)
+    if (C4 <= 4) TTL_LAUNCH_FUSED_FR(4);
+    else if (C4 <= 8) TTL_LAUNCH_FUSED_FR(8);
+    else if (C4 <= 12) TTL_LAUNCH_FUSED_FR(12);
+    else TTL_LAUNCH_FUSED_FR(16);
+#undef TTL_LAUNCH_FUSED_FR
     HIP_TRY(hipGetLastError());
     return TTL_OK;
 }

@@ -300,6 +300,8 @@ class BaseEnv(object):
         return C.c_void_p(_raw_stream(self._device_index))
 
     def _destroy_handle(self):
+        # graphs captured over the handle's buffers die with it
+        self._free_runs = {}
         if getattr(self, '_handle', None):
             self._lib.ttl_env_destroy(self._handle)
         self._handle = None

@@ -36,6 +36,9 @@ class NoisyTrackingEnvironment(TrackingEnvironment):
         self.noise_rng = env_dto.get('noise_rng')
         super().__init__(dataset_file, split_id, env_dto)
 
+    def _has_action_noise(self):
+        return self.noise > 0.
+
     def _noise_for(self, actions):
         """noisy_tracking_env.py:73-77.  sigma == 0 adds +0.0 (done inside the
         kernel) and, unlike the reference, does not advance ``rng``."""

@@ -22,6 +22,7 @@ Two flavours of the step loop are offered:
     copies nothing.  ``RLAlgorithm.validation_episode``-style loops that only
     use the harvested state get identical results from either flavour.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -51,6 +52,65 @@ class _StepInfo(dict):
 
     def __contains__(self, key):
         return key == 'continue_idx' or super().__contains__(key)
+
+
+class _FreeRun:
+    """The captured graph of one free-running step (policy + env launches) and
+    the fixed buffers it works on."""
+
+    def __init__(self, env, n, policy, record_actions):
+        dev = env.device
+        self.state = env._new_state(n)
+        self.state.zero_()
+        self.done = torch.empty(n, dtype=torch.uint8, device=dev)
+        self.reward = self.reward_sum = None
+        if env.compute_reward:
+            self.reward = torch.empty(n, dtype=torch.float64, device=dev)
+            self.reward_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.actions_log = self.step_no = None
+        if record_actions:
+            self.actions_log = torch.zeros((env.max_nb_steps + 2, n, 3),
+                                           dtype=torch.float32, device=dev)
+            self.step_no = torch.zeros(1, dtype=torch.int64, device=dev)
+        # the policy's lazy initialisations (GEMM heuristics, workspaces) must
+        # not happen under capture
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side), torch.no_grad():
+            policy(self.state)
+            policy(self.state)
+            t0.record(side)
+            for _ in range(3):
+                policy(self.state)
+            t1.record(side)
+        cur.wait_stream(side)
+        t1.synchronize()
+        #: GPU + launch time of one policy evaluation on all n rows, microseconds
+        self.policy_us = t0.elapsed_time(t1) / 3 * 1e3
+        self.graph = None
+
+    def capture(self, env, policy):
+        """Between ttl_env_freerun_begin and _end: record policy + step."""
+        n, record_actions = self.state.shape[0], self.actions_log is not None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            with torch.no_grad():
+                a = policy(self.state)
+            a = a.to(torch.float32).contiguous()
+            if a.shape != (n, 3):
+                raise ValueError(f'policy returned {tuple(a.shape)}, expected ({n}, 3)')
+            if record_actions:
+                self.actions_log.index_copy_(0, self.step_no, a[None])
+                self.step_no += 1
+            _lib.check(env._lib.ttl_env_freerun_step(
+                env._handle, a.data_ptr(), self.state.data_ptr(), env._state_pitch,
+                self.reward.data_ptr() if self.reward is not None else None,
+                self.done.data_ptr(), env._stream()), 'ttl_env_freerun_step')
+            if self.reward is not None:
+                self.reward_sum += self.reward.sum()
+            self.actions = a
 
 
 class TrackingEnvironment(BaseEnv):
@@ -310,6 +370,99 @@ class TrackingEnvironment(BaseEnv):
         self._n_active = n_cont
         self._pending = None
         return new_state, self.not_stopping
+
+    # ------------------------------------------------------------------ #
+    # free-running episode: policy + step in one HIP graph, no host in the loop
+    #: largest batch the free-running step takes (the one-launch step tail)
+    FREERUN_MAX = 16384
+
+    def _has_action_noise(self):
+        return False
+
+    def freerun_supported(self):
+        """Whether ``run_free`` can take the episode from here: a batch of at
+        most FREERUN_MAX rows between steps, no oracle criterion / bonus
+        (torch code between the step's launches) and no Gaussian action noise
+        (drawn on the host per step)."""
+        return (self._pending is None and 1 <= self._n_active <= self.FREERUN_MAX
+                and not self._use_oracle_stopping and not self._use_oracle_reward
+                and not self._has_action_noise()
+                and self.add_neighborhood_vox
+                and 0.0 < float(np.float32(self.add_neighborhood_vox)) < 1.0)
+
+    def run_free(self, policy, state, key=None, record_actions=False, max_policy_us=None):
+        """Track the current batch to exhaustion without the host in the loop
+        (what ``RLAlgorithm.validation_episode`` does with ``step_device`` /
+        ``harvest``, rl.py:58-106): ``policy(state) -> actions`` and the step's
+        launches (``ttl_env_freerun_step``) are captured once in a HIP graph
+        over fixed ``(n, .)`` buffers and replayed until the pinned survivor
+        count reads zero.  Row count, length and continue_idx parity advance in
+        device memory; rows that have stopped keep stale state rows whose
+        actions nothing reads.
+
+        ``policy`` must be torch code that can run under stream capture (no
+        host round trip) and treat rows independently.  ``key`` identifies it
+        for the graph cache (default ``id(policy)``).  Returns ``(summed reward
+        as a 0-d float64 tensor or None, number of steps)``; with
+        ``record_actions`` also the ``(steps, n, 3)`` action batches.
+
+        A replayed graph evaluates the policy on all ``n`` rows at every step,
+        while the step-by-step loop's batches shrink as streamlines stop: the
+        graph only wins while the loop is bound by launches.  With
+        ``max_policy_us`` the policy is timed once on ``n`` rows (cached per
+        key); if one evaluation takes longer, nothing is run and ``None`` is
+        returned -- the caller keeps its step-by-step loop.
+        """
+        if not self.freerun_supported():
+            raise RuntimeError('run_free: not available for this configuration')
+        n = self._n_active
+        key = (n, id(policy) if key is None else key, bool(record_actions))
+        fr = self._free_runs.get(key)
+        if fr is None:          # buffers + one timing of the policy on n rows
+            fr = self._free_runs[key] = _FreeRun(self, n, policy, record_actions)
+        if max_policy_us is not None and fr.policy_us > max_policy_us:
+            return None         # a replayed graph would lose to the shrinking batches
+        _lib.check(self._lib.ttl_env_freerun_begin(
+            self._handle, self._host_counts.data_ptr(), self._stream()),
+            'ttl_env_freerun_begin')
+        try:
+            if fr.graph is None:
+                fr.capture(self, policy)
+            fr.state[:n].copy_(state)
+            if fr.reward_sum is not None:
+                fr.reward_sum.zero_()
+            if fr.step_no is not None:
+                fr.step_no.zero_()
+            counts = self._host_counts_np
+            limit = self.max_nb_steps + 2 - self.length
+            steps = 0
+            while steps < limit:
+                fr.graph.replay()
+                steps += 1
+                if counts[0] == 0:
+                    break
+                # the host runs ahead of the GPU; keep the distance bounded so
+                # that few empty steps are queued behind the last real one
+                while steps - int(counts[2]) > 24 and counts[0] != 0:
+                    pass
+        finally:
+            n_left, length, done = C.c_int32(), C.c_int32(), C.c_int32()
+            _lib.check(self._lib.ttl_env_freerun_end(
+                self._handle, C.byref(n_left), C.byref(length), C.byref(done),
+                self._stream()), 'ttl_env_freerun_end')
+        # the host view catches up with what the device did; steps replayed
+        # after the last streamline stopped changed nothing
+        n_steps = length.value - self.length
+        if n_steps & 1:
+            self._cur ^= 1
+        self.length = length.value
+        self._n_active = n_left.value
+        self._pending = None
+        self.not_stopping = None
+        reward = fr.reward_sum.clone() if fr.reward_sum is not None else None
+        if record_actions:
+            return reward, n_steps, fr.actions_log[:n_steps].clone()
+        return reward, n_steps
 
     def _compute_stopping_flags(self, streamlines, stopping_criteria=None):
         """Which of the given streamlines should stop, and why
