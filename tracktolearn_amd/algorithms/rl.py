@@ -52,14 +52,15 @@ class RLAlgorithm(object):
         """Run the policy until every streamline of the batch has stopped
         (rl.py:58-106).  Returns the summed reward (0 when the env computes
         none, as the reference's ``sum(zeros)``)."""
-        if self._can_run_free(env):
+        if RLAlgorithm._can_run_free(self, env):
             # small batches (the default --n_actor of ttl_track among them) are
             # bound by the host's launches and by the survivor count it waits
             # for every step: run policy + step as one replayed HIP graph
             agent = self.agent
             out = env.run_free(
                 lambda s: agent.select_action(s, probabilistic=prob), initial_state,
-                key=(id(agent), float(prob)), max_policy_us=self.graph_policy_us)
+                key=(id(agent), float(prob)),
+                max_policy_us=getattr(self, 'graph_policy_us', RLAlgorithm.graph_policy_us))
             if out is not None:
                 return float(out[0]) if out[0] is not None else 0.0
             # the policy is too expensive on a full batch: step by step, with
