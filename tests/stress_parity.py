@@ -75,6 +75,17 @@ def one(rng, k):
     s_hip, s_ref = env.reset(0, N), ref.reset(0, N)
     worst = float(np.abs(s_hip.cpu().numpy() - s_ref).max())
     step = 0
+    # round 2: some episodes run on free-running steps (ttl_env_freerun_step
+    # launched eagerly for all N rows, the row count kept on the device)
+    free = bool(knobs.randint(3) == 0) and env.freerun_supported()
+    if free:
+        import ctypes
+        from tracktolearn_amd import _lib
+        fr_state = env._new_state(N)
+        fr_done = torch.empty(N, dtype=torch.uint8, device='cuda:0')
+        fr_rew = torch.empty(N, dtype=torch.float64, device='cuda:0') if reward else None
+        _lib.check(env._lib.ttl_env_freerun_begin(env._handle, env._host_counts.data_ptr(),
+                                                  env._stream()))
     wob = float(rng.choice([0.05, 0.2, 0.5]))
     with np.errstate(all='ignore'):
         while len(ref.continue_idx):
@@ -86,7 +97,21 @@ def one(rng, k):
                 nrm = np.linalg.norm(prev, axis=1, keepdims=True)
                 nrm[nrm == 0] = 1
                 a = (prev / nrm + wob * rng.standard_normal((n, 3))).astype(np.float32)
-            if rng.randint(2):
+            if free:
+                a_all = np.zeros((N, 3), np.float32)
+                a_all[:n] = a
+                a_dev = torch.from_numpy(a_all).cuda()
+                _lib.check(env._lib.ttl_env_freerun_step(
+                    env._handle, a_dev.data_ptr(), fr_state.data_ptr(), env._state_pitch,
+                    fr_rew.data_ptr() if reward else None, fr_done.data_ptr(), env._stream()))
+                ns = fr_state.cpu().numpy()[env._row_dest_view(n).cpu().numpy()]
+                d_all = fr_done.cpu().numpy().astype(bool)
+                assert d_all[n:].all(), (k, step, 'rows that left earlier report done')
+                d_hip = d_all[:n]
+                r_hip = fr_rew.cpu().numpy()[:n] if reward else np.zeros(N)
+                if reward:
+                    assert not fr_rew.cpu().numpy()[n:].any(), (k, step, 'stale reward')
+            elif rng.randint(2):
                 ns_hip, r_hip, d_hip, _ = env.step(a.copy())
                 ns = ns_hip.cpu().numpy()
             else:
@@ -101,15 +126,26 @@ def one(rng, k):
             worst = max(worst, float(np.nanmax(err)))
             assert np.nanmax(err) <= 1e-5, (k, step, 'state', float(np.nanmax(err)))
             assert np.abs(r_hip - r_ref).max() <= 1e-5, (k, step, 'reward')
-            s_hip, _ = env.harvest()
             s_ref, _ = ref.harvest()
+            if free:        # the host view follows by hand; the device needs no harvest
+                env._cur ^= 1
+                env._n_active = len(ref.continue_idx)
+                env.length += 1
+                assert int(env._host_counts_np[0]) == env._n_active, (k, step, 'count')
+            else:
+                s_hip, _ = env.harvest()
             assert np.array_equal(env.continue_idx, ref.continue_idx), (k, step, 'idx')
             step += 1
+    if free:
+        n_left, length, steps_done = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(env._lib.ttl_env_freerun_end(env._handle, ctypes.byref(n_left), ctypes.byref(length),
+                                                ctypes.byref(steps_done), env._stream()))
+        assert (n_left.value, length.value, steps_done.value) == (0, step + 1, step), (k, 'freerun_end')
     assert np.array_equal(env.flags, ref.flags), (k, 'flags')
     assert np.array_equal(env.lengths, ref.lengths), (k, 'lengths')
     assert np.array_equal(env.streamlines, ref.streamlines), (k, 'positions')
     return dict(shape=shape, C=C, K=K, theta=theta, thr=thr, step=step_mm,
-                noisy=noisy, aff=aff_dt.__name__, reward=reward, N=N, steps=step,
+                noisy=noisy, aff=aff_dt.__name__, reward=reward, N=N, steps=step, free=free,
                 worst_state_err=worst,
                 stops=(int((ref.flags & 1).astype(bool).sum()),
                        int((ref.flags & 2).astype(bool).sum()),
