@@ -262,18 +262,24 @@ int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
  *   radius outside (0, 1) voxel).  host_counts (may be NULL): 4 int32 of
  *   pinned, device-visible memory; every step writes {n_continue, n_stopped,
  *   steps done since begin} there.
- * step: actions [n][3] f32, state_out [n][state_pitch] f32, reward_out [n] f64
- *   or NULL, done_out [n] u8 -- all for the n rows active at begin.  Rows
- *   0..n_active-1 (n_active as the previous step left it) are the active rows;
- *   state rows come out survivors first (stable), then the rows that stopped
- *   in this step; rows that left earlier get done = 1, reward = 0 and keep
- *   their old state row.  No Gaussian action noise (TTL_MODE_F64DIR adds +0.0).
+ * step: covers rows 0..n_rows-1: actions [n_rows][3] f32, state_out
+ *   [n_rows][state_pitch] f32, reward_out [n_rows] f64 or NULL, done_out
+ *   [n_rows] u8.  n_rows is at most the row count at begin and must not be less
+ *   than the number of rows active now -- the count a previous step reported
+ *   through host_counts is such a bound (counts only fall), so a host loop may
+ *   shrink its action batches with the survivors without ever waiting for the
+ *   GPU; a step launched for too few rows does nothing but count itself.
+ *   Rows 0..n_active-1 (n_active as the previous step left it) are the active
+ *   rows; state rows come out survivors first (stable), then the rows that
+ *   stopped in this step; rows that left earlier get done = 1, reward = 0 and
+ *   keep their old state row.  No Gaussian action noise (TTL_MODE_F64DIR adds
+ *   +0.0).
  * end: waits for the stream, reads the device words back into the handle
  *   (which then continues as after a harvest) and returns them. */
 int ttl_env_freerun_begin(ttl_env *env, int32_t *host_counts, void *hip_stream);
-int ttl_env_freerun_step(ttl_env *env, const float *actions, float *state_out,
-                         int64_t state_pitch, double *reward_out, uint8_t *done_out,
-                         void *hip_stream);
+int ttl_env_freerun_step(ttl_env *env, const float *actions, int32_t n_rows,
+                         float *state_out, int64_t state_pitch, double *reward_out,
+                         uint8_t *done_out, void *hip_stream);
 int ttl_env_freerun_end(ttl_env *env, int32_t *n_active_out, int32_t *length_out,
                         int32_t *steps_out, void *hip_stream);
 

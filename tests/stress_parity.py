@@ -102,7 +102,7 @@ def one(rng, k):
                 a_all[:n] = a
                 a_dev = torch.from_numpy(a_all).cuda()
                 _lib.check(env._lib.ttl_env_freerun_step(
-                    env._handle, a_dev.data_ptr(), fr_state.data_ptr(), env._state_pitch,
+                    env._handle, a_dev.data_ptr(), N, fr_state.data_ptr(), env._state_pitch,
                     fr_rew.data_ptr() if reward else None, fr_done.data_ptr(), env._stream()))
                 ns = fr_state.cpu().numpy()[env._row_dest_view(n).cpu().numpy()]
                 d_all = fr_done.cpu().numpy().astype(bool)

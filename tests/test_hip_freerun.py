@@ -102,6 +102,38 @@ def test_graphed_loop_equals_the_step_by_step_loop():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('noisy,reward', [(False, True), (True, False)])
+def test_eager_free_running_episode_equals_the_oracle(noisy, reward):
+    """run_free_eager: policy + free-running step launched for the newest
+    reported survivor count, the host never waiting for a step.  The recorded
+    action batches (of whatever row count the host happened to use) replayed
+    through the oracle give the same tractogram, bit for bit."""
+    N, K = 5000, 4
+    env, subject = _env(24, N, K, noisy=noisy, reward=reward)
+    inner = _rowwise_policy(K)
+    log = []
+
+    def policy(state):
+        a = inner(state)
+        log.append(a.clone())
+        return a
+    state = env.reset(0, N)
+    got_reward, n_steps = env.run_free_eager(policy, state)
+    assert env._n_active == 0 and env.length == 1 + n_steps
+    caps = [len(a) for a in log]
+    assert caps[0] == N and caps == sorted(caps, reverse=True) and caps[-1] < N // 4
+    tract = env.get_streamlines()
+    ref = _oracle(env, subject, noisy=noisy, K=K, reward=reward)
+    total = _replay_through_oracle(ref, [a.cpu().numpy() for a in log[:n_steps]], N)
+    lines, _, flags = ref.get_streamlines()
+    assert np.array_equal(tract.data_per_streamline['flags'], flags)
+    assert np.array_equal(env.lengths, ref.lengths)
+    for a, b in zip(tract.streamlines, lines):
+        assert np.array_equal(a, b)
+    if reward:
+        assert abs(float(got_reward) - total) <= 1e-9 * max(1.0, abs(total))
+
+
 def test_validation_episode_takes_the_graph_with_a_network(monkeypatch):
     """Tracker.track_and_validate with a SACAuto policy: the graphed loop is
     taken (default) and tracks like the step-by-step loop (TTL_GRAPH_EPISODE=0).
@@ -145,7 +177,7 @@ def test_free_running_steps_hand_the_episode_back():
     buf = env._new_state(N)
     buf[:N].copy_(state)
     a = policy(buf).contiguous()
-    step_args = (h, a.data_ptr(), buf.data_ptr(), env._state_pitch, reward.data_ptr(),
+    step_args = (h, a.data_ptr(), N, buf.data_ptr(), env._state_pitch, reward.data_ptr(),
                  done.data_ptr(), env._stream())
     assert lib.ttl_env_freerun_step(*step_args) == _lib.ERR_STATE        # begin first
     assert lib.ttl_env_freerun_end(h, None, None, None, env._stream()) == _lib.ERR_STATE
@@ -153,18 +185,26 @@ def test_free_running_steps_hand_the_episode_back():
     assert lib.ttl_env_freerun_begin(h, None, env._stream()) == _lib.ERR_STATE
     with pytest.raises(_lib.TTLError):
         env.step_device(a)                    # the handle is free-running
+    assert lib.ttl_env_freerun_step(h, a.data_ptr(), N + 1, buf.data_ptr(), env._state_pitch,
+                                    reward.data_ptr(), done.data_ptr(),
+                                    env._stream()) == _lib.ERR_INVALID
+    # a launch that does not cover the active rows only counts itself
+    _lib.check(lib.ttl_env_freerun_step(h, a.data_ptr(), N - 7, buf.data_ptr(), env._state_pitch,
+                                        reward.data_ptr(), done.data_ptr(), env._stream()))
+    torch.cuda.synchronize()
+    assert env._host_counts_np[:3].tolist() == [N, 0, 1]
     log, rewards = [], 0.0
     for _ in range(3):
         a = policy(buf).contiguous()
         log.append(a.cpu().numpy())
-        _lib.check(lib.ttl_env_freerun_step(h, a.data_ptr(), buf.data_ptr(), env._state_pitch,
+        _lib.check(lib.ttl_env_freerun_step(h, a.data_ptr(), N, buf.data_ptr(), env._state_pitch,
                                             reward.data_ptr(), done.data_ptr(), env._stream()))
         rewards += float(reward.sum())
     n_left, length, steps = C.c_int32(), C.c_int32(), C.c_int32()
     _lib.check(lib.ttl_env_freerun_end(h, C.byref(n_left), C.byref(length), C.byref(steps),
                                        env._stream()))
-    assert steps.value == 3 and length.value == 4
-    assert int(env._host_counts_np[0]) == n_left.value and int(env._host_counts_np[2]) == 3
+    assert steps.value == 4 and length.value == 4        # the skipped launch counted itself
+    assert int(env._host_counts_np[0]) == n_left.value and int(env._host_counts_np[2]) == 4
     # hand back to the host loop
     env.length, env._n_active = length.value, n_left.value
     env._cur ^= 1                                  # three steps: odd
@@ -185,9 +225,10 @@ def test_free_running_steps_hand_the_episode_back():
     assert abs(rewards - total) <= 1e-9 * max(1.0, abs(total))
 
 
-def test_expensive_policies_keep_the_step_by_step_loop(monkeypatch):
+def test_expensive_policies_run_free_without_a_graph(monkeypatch):
     """run_free times the policy once on the full batch; above max_policy_us it
-    declines (None) and validation_episode falls back to shrinking batches."""
+    declines (None) and validation_episode launches policy + free-running step
+    itself, on batches that shrink with the reported survivor count."""
     from tracktolearn_amd.algorithms.sac_auto import SACAuto
     N, K = 1200, 4
     env, _ = _env(20, N, K, noisy=True, reward=False)
@@ -200,6 +241,7 @@ def test_expensive_policies_keep_the_step_by_step_loop(monkeypatch):
     assert env._n_active == 0 and env.length > 2
     (fr,) = env._free_runs.values()
     assert fr.graph is None and fr.policy_us > 0.0
+    assert list(env._free_bufs) == [N]          # the eager free-running loop ran
 
 
 def test_free_running_refuses_large_batches_and_noise():

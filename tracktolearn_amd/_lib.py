@@ -97,8 +97,8 @@ SYMBOLS = {
     'ttl_env_harvest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_void_p]),
     'ttl_env_freerun_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    'ttl_env_freerun_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttl_env_freerun_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttl_env_freerun_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.c_void_p]),

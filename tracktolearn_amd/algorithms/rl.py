@@ -61,10 +61,13 @@ class RLAlgorithm(object):
                 lambda s: agent.select_action(s, probabilistic=prob), initial_state,
                 key=(id(agent), float(prob)),
                 max_policy_us=getattr(self, 'graph_policy_us', RLAlgorithm.graph_policy_us))
-            if out is not None:
-                return float(out[0]) if out[0] is not None else 0.0
-            # the policy is too expensive on a full batch: step by step, with
-            # batches that shrink as streamlines stop
+            if out is None:
+                # the policy is too expensive to run on the full batch at every
+                # step: launch it on the newest reported survivor count instead,
+                # still without ever waiting for a step
+                out = env.run_free_eager(
+                    lambda s: agent.select_action(s, probabilistic=prob), initial_state)
+            return float(out[0]) if out[0] is not None else 0.0
         running_reward = None
         state = initial_state
         while state.shape[0] > 0:

@@ -427,16 +427,19 @@ __global__ __launch_bounds__(BLOCK) void k_advance_fr(
     const int *live = P.counts + TTL_FR_LIVE;
     int n_active = live[0];
     const int L = live[1], cur = live[2];
-    // a full history takes no more points (cannot happen while rows are
-    // active: the LENGTH criterion has stopped them; guards the history write)
-    if (L < 1 || L > P.max_nb_steps || n_active > n_cap) n_active = 0;
+    // A launch that does not cover the active rows, or a full history (cannot
+    // happen while rows are active: the LENGTH criterion has stopped them;
+    // guards the history write): the step does nothing but count itself.
+    const bool skip = L < 1 || L > P.max_nb_steps || n_active > n_cap;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int *snap = P.counts + TTL_FR_SNAP;
         snap[0] = n_active;
         snap[1] = L;
         snap[2] = cur;
         snap[3] = live[3];
+        snap[4] = skip ? 1 : 0;
     }
+    if (skip) n_active = 0;
     const int *idx = cur ? idx_b : idx_a;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < n_active;
@@ -1505,18 +1508,21 @@ int ttl_env_freerun_begin(ttl_env *env, int32_t *host_counts, void *hip_stream) 
     return TTL_OK;
 }
 
-int ttl_env_freerun_step(ttl_env *env, const float *actions, float *state_out,
+int ttl_env_freerun_step(ttl_env *env, const float *actions, int32_t n_rows, float *state_out,
                          int64_t state_pitch, double *reward_out, uint8_t *done_out,
                          void *hip_stream) {
     if (!env || !actions || !state_out || !done_out)
         return fail(TTL_ERR_INVALID, "ttl_env_freerun_step: null argument");
     if (!env->fr_cap) return fail(TTL_ERR_STATE, "ttl_env_freerun_step: call ttl_env_freerun_begin first");
+    if (n_rows < 1 || n_rows > env->fr_cap)
+        return fail(TTL_ERR_INVALID, "ttl_env_freerun_step: n_rows=%d outside [1, %d]", n_rows,
+                    env->fr_cap);
     const ttl_env_desc &d = env->d;
     const int64_t width = 7LL * d.n_coef + 3LL * d.n_dirs;
     if (state_pitch < width)
         return fail(TTL_ERR_INVALID, "ttl_env_freerun_step: state_pitch too small");
     hipStream_t s = (hipStream_t)hip_stream;
-    const int n_cap = env->fr_cap;
+    const int n_cap = n_rows;
     const int nb = (n_cap + BLOCK - 1) / BLOCK;
     // launches only: nothing below waits, copies or asks the runtime anything,
     // so the call may run under stream capture

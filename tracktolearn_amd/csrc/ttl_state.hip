@@ -538,6 +538,14 @@ __global__ __launch_bounds__(BLOCK, 4) void k_prefix_state_fr(
     float *__restrict__ out, long long pitch, int *__restrict__ host_word) {
     const int *snap = P.counts + TTL_FR_SNAP;
     const int n_active = snap[0], L = snap[1], cur = snap[2], seq = snap[3] + 1;
+    if (snap[4]) {      // k_advance_fr skipped the step: only the step counter moves
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            P.counts[TTL_FR_LIVE + 3] = seq;
+            if (host_word)
+                __hip_atomic_store(host_word + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     prefix_state_body<LPS, MERGE_TAIL, true>(P, cur ? idx_b : idx_a, cur ? idx_a : idx_b,
                                              n_active, n_blocks, TTL_ORDER_PARTITION, L + 1,
                                              out, pitch, host_word, seq, cur);

@@ -302,6 +302,7 @@ class BaseEnv(object):
     def _destroy_handle(self):
         # graphs captured over the handle's buffers die with it
         self._free_runs = {}
+        self._free_bufs = {}
         if getattr(self, '_handle', None):
             self._lib.ttl_env_destroy(self._handle)
         self._handle = None

@@ -105,7 +105,7 @@ class _FreeRun:
                 self.actions_log.index_copy_(0, self.step_no, a[None])
                 self.step_no += 1
             _lib.check(env._lib.ttl_env_freerun_step(
-                env._handle, a.data_ptr(), self.state.data_ptr(), env._state_pitch,
+                env._handle, a.data_ptr(), n, self.state.data_ptr(), env._state_pitch,
                 self.reward.data_ptr() if self.reward is not None else None,
                 self.done.data_ptr(), env._stream()), 'ttl_env_freerun_step')
             if self.reward is not None:
@@ -389,6 +389,73 @@ class TrackingEnvironment(BaseEnv):
                 and not self._has_action_noise()
                 and self.add_neighborhood_vox
                 and 0.0 < float(np.float32(self.add_neighborhood_vox)) < 1.0)
+
+    def run_free_eager(self, policy, state, lookahead=2):
+        """The same episode as ``run_free`` without a graph, for policies whose
+        cost grows with the batch (the reference's default 1024-wide networks
+        are bound by their GEMMs): the host launches policy + free-running step
+        for ``cap`` rows, where ``cap`` is the newest survivor count the GPU has
+        reported in pinned memory -- an upper bound of the rows active now, since
+        counts only fall -- and never waits for a step to finish, only for the
+        GPU not to fall more than ``lookahead`` steps behind (so that ``cap``
+        follows the survivors closely).  The GPU runs back to back; the policy's
+        batches shrink as in the step-by-step loop.  Returns ``(summed reward
+        as a 0-d float64 tensor or None, number of steps)``."""
+        if not self.freerun_supported():
+            raise RuntimeError('run_free_eager: not available for this configuration')
+        n = self._n_active
+        dev = self.device
+        buf = self._free_bufs.get(n) if hasattr(self, '_free_bufs') else None
+        if buf is None:
+            if not hasattr(self, '_free_bufs'):
+                self._free_bufs = {}
+            reward = torch.empty(n, dtype=torch.float64, device=dev) \
+                if self.compute_reward else None
+            buf = self._free_bufs[n] = (self._new_state(n),
+                                        torch.empty(n, dtype=torch.uint8, device=dev), reward)
+        state_buf, done, reward = buf
+        state_buf[:n].copy_(state)
+        reward_sum = torch.zeros((), dtype=torch.float64, device=dev) \
+            if reward is not None else None
+        _lib.check(self._lib.ttl_env_freerun_begin(
+            self._handle, self._host_counts.data_ptr(), self._stream()),
+            'ttl_env_freerun_begin')
+        try:
+            counts = self._host_counts_np
+            step_fn, handle, pitch = self._lib.ttl_env_freerun_step, self._handle, self._state_pitch
+            reward_ptr = reward.data_ptr() if reward is not None else None
+            state_ptr, done_ptr = state_buf.data_ptr(), done.data_ptr()
+            limit = self.max_nb_steps + 2 - self.length
+            steps, cap = 0, n
+            while steps < limit:
+                c = int(counts[0])
+                if c == 0:
+                    break
+                cap = min(cap, c)
+                with torch.no_grad():
+                    a = policy(state_buf[:cap])
+                if a.dtype is not torch.float32 or not a.is_contiguous():
+                    a = a.to(torch.float32).contiguous()
+                _lib.check(step_fn(handle, a.data_ptr(), cap, state_ptr, pitch, reward_ptr,
+                                   done_ptr, self._stream()), 'ttl_env_freerun_step')
+                if reward is not None:
+                    reward_sum += reward[:cap].sum()
+                steps += 1
+                while steps - int(counts[2]) > lookahead:
+                    pass
+        finally:
+            n_left, length, done_steps = C.c_int32(), C.c_int32(), C.c_int32()
+            _lib.check(self._lib.ttl_env_freerun_end(
+                self._handle, C.byref(n_left), C.byref(length), C.byref(done_steps),
+                self._stream()), 'ttl_env_freerun_end')
+        n_steps = length.value - self.length
+        if n_steps & 1:
+            self._cur ^= 1
+        self.length = length.value
+        self._n_active = n_left.value
+        self._pending = None
+        self.not_stopping = None
+        return reward_sum, n_steps
 
     def run_free(self, policy, state, key=None, record_actions=False, max_policy_us=None):
         """Track the current batch to exhaustion without the host in the loop
