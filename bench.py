@@ -376,6 +376,7 @@ def main(argv=None):
     # ---- whole episode to exhaustion, outside the K-step
     # windows of the contract ------------------------------------------------
     ep = None
+    free_tail = os.environ.get('TTL_BENCH_FREE_TAIL', '1') != '0'
     if not args.no_whole_episode:
         # two episodes, the second one reported (the first one of a process
         # runs slower: allocator growth and first-use effects a tracking run
@@ -384,8 +385,17 @@ def main(argv=None):
             state = env.reset(0, N_ACTOR)
             torch.cuda.synchronize()
             t_ep = time.perf_counter()
-            ep_units, ep_steps = 0, 0
+            ep_units, ep_steps, free_steps = 0, 0, 0
             while env._n_active:
+                if free_tail and env.freerun_supported():
+                    # from 16 384 rows down a step is bound by the host waiting
+                    # for its survivor count: free-running steps, launched for
+                    # the newest count the GPU has reported, never waited for
+                    left = env._n_active
+                    _, free_steps = env.run_free_eager(
+                        lambda st: env.scripted_actions_free(st, seed, WOBBLE), state)
+                    ep_steps += free_steps
+                    break
                 ep_units += env._n_active
                 actions = env.scripted_actions(state, ep_steps, seed, WOBBLE)
                 env.step_device(actions)
@@ -393,9 +403,12 @@ def main(argv=None):
                 ep_steps += 1
             torch.cuda.synchronize()
             t_ep = time.perf_counter() - t_ep
+            # streamline-steps = points added = sum(lengths - 1)
+            ep_units = int(env._buf_lengths[:N_ACTOR].sum().item()) - N_ACTOR
             first = ep
             ep = {'streamline_steps_per_s_rank0': ep_units / t_ep, 'steps': ep_steps,
                   'streamline_steps': ep_units, 'ms': t_ep * 1e3,
+                  'free_running_tail_steps': free_steps,
                   'order_refresh_every': env.SPATIAL_ORDER_REFRESH}
             if first is not None:
                 ep['first_episode_ms'] = first['ms']
@@ -523,6 +536,10 @@ def main(argv=None):
         }
         if ep is not None:
             line['whole_episode'] = ep
+        if getattr(env, '_sh_tuned', None):
+            # gather time of every candidate placement of the SH volume (ms per launch at
+            # 131 072 streamlines); the fastest was kept (env.py:_tune_volume_placement)
+            line['volume_placement_candidates_ms'] = env._sh_tuned
         if collate_ms is not None:
             line['collate_ms'] = collate_ms
             line['collate_bytes_to_root'] = collate_bytes

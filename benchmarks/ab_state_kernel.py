@@ -22,8 +22,9 @@ import bench  # noqa: E402
 
 def parse(variant):
     """'k=4,r=16,fine=1,ls=1' -> dict (k: TTL_STATE_KERNEL, r: refresh period,
-    fine: TTL_ORDER_KEY, ls: TTL_LOCAL_SORT, lay: TTL_SH_LAYOUT)."""
-    cfg = {'k': '4', 'r': '16', 'fine': '0', 'ls': '1', 'lay': 'brick4', 'st': '0', 'd': '96'}
+    fine: TTL_ORDER_KEY, ls: TTL_LOCAL_SORT, lay: TTL_SH_LAYOUT, st: TTL_STORE_FLAVOUR,
+    cv: TTL_CONTIGUOUS_VOLUME, vc: TTL_VOLUME_CANDIDATES)."""
+    cfg = {'k': '4', 'r': '16', 'fine': '0', 'ls': '1', 'lay': 'brick4', 'st': '0', 'd': '96', 'cv': '1', 'vc': '4'}
     for part in str(variant).split(','):
         if part:
             key, val = part.split('=')
@@ -48,6 +49,8 @@ def make(variant, subject):
     os.environ['TTL_ORDER_KEY'] = cfg['fine']
     os.environ['TTL_SH_LAYOUT'] = cfg['lay']
     os.environ['TTL_STORE_FLAVOUR'] = cfg['st']
+    os.environ['TTL_CONTIGUOUS_VOLUME'] = cfg['cv']
+    os.environ['TTL_VOLUME_CANDIDATES'] = cfg['vc']
     env = bench.make_env(subject, 'cuda:0', 0)
     env.SPATIAL_ORDER_REFRESH = int(cfg['r'])
     env._fine = cfg['fine']
@@ -113,6 +116,7 @@ def main():
                           'k_state_ms_per_instance': per_copy,
                           'k_advance_ms_median': float(np.median(r['adv'])),
                           'Msteps_per_s_median': float(np.median(r['rate'])) / 1e6,
+                          'volume_candidates_ms': [e._sh_tuned for e, _ in envs[v]],
                           'max_abs_diff_vs_first': max(d for _, d in envs[v])}), flush=True)
 
 

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Counter comparison of the gather's two modes (run under rocprofv3 --pmc):
+creates env instances until a fast and a slow one exist, then runs
+fast / slow / fast / slow windows back to back and writes, to the file named by
+PLACEMENT_PMC_OUT, how many gather launches precede that section, so that the
+per-dispatch counter rows can be split (13 gather launches per window).
+
+    rocprofv3 --kernel-trace --pmc <counters> -d out -- python3 benchmarks/placement_pmc.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ['TTL_VOLUME_CANDIDATES'] = '1'
+import bench  # noqa: E402
+from benchmarks.ab_state_kernel import window  # noqa: E402
+from benchmarks.placement_probe import timed  # noqa: E402
+
+LAUNCHES = [0]
+
+
+def counted_window(env):
+    window(env)
+    LAUNCHES[0] += 13           # reset + 12 steps
+
+
+def main():
+    subject = bench.make_subject()
+    envs, times = [], []
+    for i in range(10):
+        env = bench.make_env(subject, 'cuda:0', 0)
+        env.reset(0, bench.N_ACTOR)
+        LAUNCHES[0] += 1
+        counted_window(env)
+        envs.append(env)
+        ms = []
+        for _ in range(3):
+            env.profile_begin(64, classes=('state',))
+            counted_window(env)
+            t, c = env.profile_end()['state']
+            ms.append(t / max(c, 1))
+        times.append(float(np.median(ms)))
+        if len(envs) >= 3 and max(times) / min(times) > 1.06:
+            break
+    out = dict(instances_ms=[round(t, 4) for t in times])
+    if max(times) / min(times) <= 1.06:
+        out['note'] = 'one mode only'
+    else:
+        fast, slow = envs[int(np.argmin(times))], envs[int(np.argmax(times))]
+        out['launches_before'] = LAUNCHES[0]
+        for env in (fast, slow, fast, slow):
+            counted_window(env)
+        out['sequence'] = ['fast', 'slow', 'fast', 'slow']
+    with open(os.environ.get('PLACEMENT_PMC_OUT', '/dev/stdout'), 'w') as f:
+        f.write(json.dumps(out) + '\n')
+
+
+if __name__ == '__main__':
+    main()

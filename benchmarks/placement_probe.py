@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Why do env instances of one process gather at 0.176 or at 0.20 ms?  Creates
+instances of bench.py's env with allocator churn in between, prints the device
+addresses of their large buffers next to the gather's launch time, then moves
+single buffers of one instance to fresh allocations (same contents) to see which
+allocation the time follows.
+
+    python benchmarks/placement_probe.py [instances]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from benchmarks.ab_state_kernel import window  # noqa: E402
+
+
+_REF = {}
+
+
+def reference_kernel_ms():
+    """A fixed yardstick next to every measurement: 256 MiB copied device to
+    device (bandwidth) and a 4096^3 fp32 GEMM (clock)."""
+    if not _REF:
+        _REF['a'] = torch.empty(256 << 20, dtype=torch.uint8, device='cuda:0')
+        _REF['b'] = torch.empty_like(_REF['a'])
+        _REF['x'] = torch.randn(4096, 4096, device='cuda:0')
+        _REF['y'] = torch.randn(4096, 4096, device='cuda:0')
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for _ in range(2):
+        _REF['b'].copy_(_REF['a'])
+        torch.mm(_REF['x'], _REF['y'])
+    e[0].record()
+    for _ in range(5):
+        _REF['b'].copy_(_REF['a'])
+    e[1].record()
+    for _ in range(5):
+        torch.mm(_REF['x'], _REF['y'])
+    e[2].record()
+    torch.cuda.synchronize()
+    return round(e[0].elapsed_time(e[1]) / 5, 4), round(e[1].elapsed_time(e[2]) / 5, 4)
+
+
+def timed(env, rounds=3):
+    ms = []
+    for _ in range(rounds):
+        env.profile_begin(64, classes=('state',))
+        window(env)
+        t, c = env.profile_end()['state']
+        ms.append(t / max(c, 1))
+    return float(np.median(ms))
+
+
+def rehandle(env):
+    env._destroy_handle()
+    env._n_max = 0
+    env.reset(0, bench.N_ACTOR)
+    window(env)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    rng = np.random.RandomState(0)
+    subject = bench.make_subject()
+    envs, junk = [], []
+    for i in range(n):
+        # churn: holes of odd sizes in front of the next instance's buffers
+        junk.append(torch.empty(int(rng.randint(1, 400)) << 20, dtype=torch.uint8, device='cuda:0'))
+        if i % 2:
+            junk.pop(0)
+        env = bench.make_env(subject, 'cuda:0', 0)
+        env.reset(0, bench.N_ACTOR)
+        window(env)
+        envs.append(env)
+    times = []
+    for i, env in enumerate(envs):
+        ms = timed(env)
+        times.append(ms)
+        print(json.dumps(dict(i=i, ms=round(ms, 4), ref=reference_kernel_ms(),
+                              sh=hex(env._sh_packed.data_ptr()),
+                              hist=hex(env._buf_streamlines.data_ptr()),
+                              ws=hex(env._buf_ws.data_ptr()))), flush=True)
+    slow = int(np.argmax(times))
+    env = envs[slow]
+    print(json.dumps(dict(moving_buffers_of=slow, ms=round(times[slow], 4))), flush=True)
+    for trial in range(6):
+        junk.append(torch.empty(int(rng.randint(1, 300)) << 20, dtype=torch.uint8, device='cuda:0'))
+        old = env._sh_packed
+        env._sh_packed = old.clone()
+        rehandle(env)
+        print(json.dumps(dict(moved='sh', to=hex(env._sh_packed.data_ptr()),
+                              hist=hex(env._buf_streamlines.data_ptr()),
+                              ws=hex(env._buf_ws.data_ptr()),
+                              ms=round(timed(env), 4), ref=reference_kernel_ms())), flush=True)
+        del old
+    for trial in range(3):
+        junk.append(torch.empty(int(rng.randint(1, 300)) << 20, dtype=torch.uint8, device='cuda:0'))
+        rehandle(env)           # new history / workspace / idx buffers, same volume
+        print(json.dumps(dict(moved='hist+ws', sh=hex(env._sh_packed.data_ptr()),
+                              hist=hex(env._buf_streamlines.data_ptr()),
+                              ws=hex(env._buf_ws.data_ptr()),
+                              ms=round(timed(env), 4), ref=reference_kernel_ms())), flush=True)
+    for i, env in enumerate(envs):
+        print(json.dumps(dict(i=i, final_ms=round(timed(env), 4), ref=reference_kernel_ms())), flush=True)
+
+
+if __name__ == '__main__':
+    main()

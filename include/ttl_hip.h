@@ -141,6 +141,22 @@ size_t ttl_env_workspace_bytes(int32_t n_max);
 /* Number of voxel records ttl_pack_sh_volume() writes for a volume. */
 int64_t ttl_sh_volume_records(const int32_t *dim /*[3]*/, int32_t layout);
 
+/* Device memory for a volume the step gathers from (the packed SH volume):
+ * with try_contiguous physically contiguous (hipExtMallocWithFlags,
+ * hipDeviceMallocContiguous) when the driver grants it, plain hipMalloc
+ * otherwise; *contiguous_out says which.  device < 0: the calling thread's
+ * current device.  These two entry points are the only ones that own device
+ * memory; everything else is borrowed.  They exist because WHERE the 170 MB
+ * volume of the bench lands in physical memory moves the state gather between
+ * 0.18 and 0.20 ms on the same GPU: the host classes pack a
+ * subject's volume into a few allocations obtained here, time the step's own
+ * gather on each at the first large reset and keep the fastest; the caching
+ * allocator would hand the same block back every time. */
+int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void **out,
+                     int32_t *contiguous_out);
+int ttl_volume_free(void *ptr);
+
+
 /* Repack an SH volume [X][Y][Z][C] f32 (the layout of
  * TTL/environments/env.py:169-180 `data_volume`) into 16-byte aligned voxel
  * records of coef_pitch floats, zero padded, in `layout` order; dst holds
@@ -282,6 +298,12 @@ int ttl_env_freerun_step(ttl_env *env, const float *actions, int32_t n_rows,
                          uint8_t *done_out, void *hip_stream);
 int ttl_env_freerun_end(ttl_env *env, int32_t *n_active_out, int32_t *length_out,
                         int32_t *steps_out, void *hip_stream);
+/* Measurement only: ttl_scripted_actions() for a free-running step -- the row
+ * count, the step number (length - 1) and the live continue_idx buffer are
+ * read from the device words; rows 0..min(n_active, n_rows)-1 are written. */
+int ttl_env_freerun_scripted_actions(ttl_env *env, const float *state, int64_t state_pitch,
+                                     int32_t dir_offset, int32_t n_rows, uint32_t seed,
+                                     float wobble, float *actions_out, void *hip_stream);
 
 /* BaseEnv._compute_stopping_flags (env.py:567-603) on caller-supplied points:
  * tail [n][3][3] f32 holds the last three points (oldest first) of n

@@ -255,3 +255,30 @@ def test_free_running_refuses_large_batches_and_noise():
     assert env.freerun_supported()
     env.noise = 0.1
     assert not env.freerun_supported()
+
+
+def test_scripted_policy_episode_with_a_free_running_tail():
+    """bench.py's whole-episode loop: step by step down to 16 384 rows, then
+    free-running steps with the scripted policy reading row count and step
+    number on the device.  Same tractogram as the all-step-by-step episode."""
+    N, K = 20000, 4
+    env, _ = _env(28, N, K, noisy=False, reward=False, max_length=40.0)
+
+    def episode(free_tail):
+        state = env.reset(0, N)
+        step, free_steps = 0, 0
+        while env._n_active:
+            if free_tail and env.freerun_supported():
+                _, free_steps = env.run_free_eager(
+                    lambda st: env.scripted_actions_free(st, 7, 0.05), state)
+                break
+            env.step_device(env.scripted_actions(state, step, 7, 0.05))
+            state, _ = env.harvest()
+            step += 1
+        return step, free_steps, env.lengths.copy(), env.flags.copy(), env.streamlines.copy()
+
+    s0, f0, len0, fl0, pts0 = episode(False)
+    s1, f1, len1, fl1, pts1 = episode(True)
+    assert f0 == 0 and f1 > 0 and s1 >= 1 and s1 + f1 == s0
+    assert np.array_equal(len0, len1) and np.array_equal(fl0, fl1)
+    assert np.array_equal(pts0, pts1)

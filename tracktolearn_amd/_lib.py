@@ -74,6 +74,9 @@ class EnvDesc(C.Structure):
 SYMBOLS = {
     'ttl_env_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'ttl_sh_volume_records': (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),
+    'ttl_volume_alloc': (C.c_int, [C.c_int32, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_int32)]),
+    'ttl_volume_free': (C.c_int, [C.c_void_p]),
     'ttl_pack_sh_volume': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     'ttl_mask_classes': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_double,
@@ -99,6 +102,9 @@ SYMBOLS = {
     'ttl_env_freerun_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttl_env_freerun_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ttl_env_freerun_scripted_actions': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64,
+                                                   C.c_int32, C.c_int32, C.c_uint32,
+                                                   C.c_float, C.c_void_p, C.c_void_p]),
     'ttl_env_freerun_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.c_void_p]),
@@ -154,6 +160,27 @@ def load():
                        f'({C.sizeof(EnvDesc)} B)')
     _lib = lib
     return lib
+
+
+class DeviceVolume:
+    """Device memory from ``ttl_volume_alloc`` (on request physically contiguous
+    when the driver grants it), exposed through ``__cuda_array_interface__`` so that
+    ``torch.as_tensor(vol, device=...)`` wraps it without a copy; the tensor
+    keeps this object alive, ``__del__`` returns the memory."""
+
+    def __init__(self, device_index, nbytes, try_contiguous=False):
+        lib = load()
+        ptr, contiguous = C.c_void_p(), C.c_int32()
+        check(lib.ttl_volume_alloc(int(device_index), int(nbytes), 1 if try_contiguous else 0,
+                                   C.byref(ptr), C.byref(contiguous)), 'ttl_volume_alloc')
+        self.ptr, self.nbytes, self.contiguous = ptr.value, int(nbytes), bool(contiguous.value)
+        self.__cuda_array_interface__ = {'shape': (self.nbytes,), 'typestr': '|u1',
+                                         'data': (self.ptr, False), 'version': 2}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, 'ptr', None), None
+        if ptr and _lib is not None:
+            _lib.ttl_volume_free(ptr)
 
 
 def check(code, what=''):

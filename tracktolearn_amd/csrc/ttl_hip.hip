@@ -804,6 +804,37 @@ __global__ __launch_bounds__(BLOCK) void k_scripted_actions(
     actions[(size_t)i * 3 + 2] = a2;
 }
 
+// the same policy for a free-running step: row count, step number and the live
+// continue_idx buffer from the device words (see k_advance_fr)
+__global__ __launch_bounds__(BLOCK) void k_scripted_actions_fr(
+    EnvParams P, const float *__restrict__ state, long long pitch, int dir_offset,
+    const int *__restrict__ idx_a, const int *__restrict__ idx_b, int n_rows,
+    unsigned seed, float wobble, float *__restrict__ actions) {
+    const int *live = P.counts + TTL_FR_LIVE;
+    const int n = min(live[0], n_rows);
+    const unsigned step = (unsigned)(live[1] - 1);
+    const int *idx = live[2] ? idx_b : idx_a;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned gid = (unsigned)idx[i];
+    const float n0 = scripted_noise(seed, step, gid, 0);
+    const float n1 = scripted_noise(seed, step, gid, 1);
+    const float n2 = scripted_noise(seed, step, gid, 2);
+    float a0 = n0, a1 = n1, a2 = n2;
+    if (step > 0) {
+        const float *row = state + (size_t)i * (size_t)pitch + dir_offset;
+        const float px = row[0], py = row[1], pz = row[2];
+        float s = sqrtf((px * px + py * py) + pz * pz);
+        if (!(s > 0.0f)) s = 1.0f;
+        a0 = px / s + wobble * n0;
+        a1 = py / s + wobble * n1;
+        a2 = pz / s + wobble * n2;
+    }
+    actions[(size_t)i * 3 + 0] = a0;
+    actions[(size_t)i * 3 + 1] = a1;
+    actions[(size_t)i * 3 + 2] = a2;
+}
+
 // ---------------------------------------------------------------------------
 // k_mask_classes: for every cell (the integer part of a sample coordinate)
 // the min / max of the 64 mirror-folded coefficient taps a sample in that
@@ -920,6 +951,38 @@ int64_t ttl_sh_volume_records(const int32_t *dim, int32_t layout) {
     if (layout == TTL_SH_BRICK4)
         return (int64_t)((dim[0] + 3) / 4) * ((dim[1] + 3) / 4) * ((dim[2] + 3) / 4) * 64;
     return (int64_t)dim[0] * dim[1] * dim[2];
+}
+
+// Device memory for a gathered volume: on request physically contiguous when
+// the driver can give that, ordinary hipMalloc otherwise.
+int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void **out,
+                     int32_t *contiguous_out) {
+    if (!out || bytes == 0) return fail(TTL_ERR_INVALID, "ttl_volume_alloc: bad arguments");
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
+    if (device >= 0 && device != prev) HIP_TRY(hipSetDevice(device));
+    void *p = nullptr;
+    int contiguous = 0;
+    if (try_contiguous) {
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) == hipSuccess && p)
+            contiguous = 1;
+        else {
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (!p) e = hipMalloc(&p, bytes);
+    if (device >= 0 && device != prev) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return fail(TTL_ERR_HIP, "ttl_volume_alloc: %s", hipGetErrorString(e));
+    *out = p;
+    if (contiguous_out) *contiguous_out = contiguous;
+    return TTL_OK;
+}
+
+int ttl_volume_free(void *ptr) {
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return TTL_OK;
 }
 
 int ttl_pack_sh_volume(const float *src, float *dst, const int32_t *dim, int32_t n_coef,
@@ -1071,6 +1134,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.slot_rec = e->state_kernel != 2;
     P.xcd_remap = 1;
     if (const char *v = getenv("TTL_XCD_REMAP")) P.xcd_remap = atoi(v);
+    P.xcd_rot = 0;
+    if (const char *v = getenv("TTL_XCD_ROTATE")) P.xcd_rot = atoi(v) & 7;
     P.store_flavour = 0;
     if (const char *v = getenv("TTL_STORE_FLAVOUR")) P.store_flavour = atoi(v);
     e->side = nullptr;
@@ -1536,6 +1601,21 @@ int ttl_env_freerun_step(ttl_env *env, const float *actions, int32_t n_rows, flo
     HIP_TRY(hipGetLastError());
     return ttl_detail_launch_fused_tail_fr(env->P, d.idx_a, d.idx_b, n_cap, state_out,
                                            state_pitch, env->fr_host_word, s);
+}
+
+int ttl_env_freerun_scripted_actions(ttl_env *env, const float *state, int64_t state_pitch,
+                                     int32_t dir_offset, int32_t n_rows, uint32_t seed,
+                                     float wobble, float *actions_out, void *hip_stream) {
+    if (!env || !state || !actions_out || n_rows < 1 || dir_offset < 0 ||
+        state_pitch < dir_offset + 3)
+        return fail(TTL_ERR_INVALID, "ttl_env_freerun_scripted_actions: bad arguments");
+    if (!env->fr_cap || n_rows > env->fr_cap)
+        return fail(TTL_ERR_STATE, "ttl_env_freerun_scripted_actions: not free-running for %d rows", n_rows);
+    hipLaunchKernelGGL(k_scripted_actions_fr, dim3((n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0,
+                       (hipStream_t)hip_stream, env->P, state, (long long)state_pitch, dir_offset,
+                       env->d.idx_a, env->d.idx_b, n_rows, seed, wobble, actions_out);
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
 }
 
 int ttl_env_freerun_end(ttl_env *env, int32_t *n_active_out, int32_t *length_out,

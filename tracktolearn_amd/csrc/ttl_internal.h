@@ -67,6 +67,7 @@ struct EnvParams {
     int slot_rec;      // the gather reads the slot records (0: resolves proc -> idx/row_dest/head itself)
     int store_flavour; // cache policy of the state-row stores (TTL_STORE_FLAVOUR, see store16)
     int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
+    int xcd_rot;       // XCD x gathers range (x + xcd_rot) & 7 of the processing order
     int *counts;       // {n_continue, n_stopped}; 64 ints: the free-running step's words live here too
 };
 

@@ -214,6 +214,30 @@ __device__ __forceinline__ void store16(float *o, v4f v, int flavour) {
 
 template <bool MERGE_TAIL>
 __device__ __forceinline__ void put4(int flavour, float *o, f4 a, int c, int C) {
+    if (MERGE_TAIL && (flavour & 8)) {
+        // C mod 4 is wave-uniform: a scalar branch picks the one shifted vector
+        // the last lane needs (3 DPP moves and 4 selects at most, none when C is
+        // a multiple of 4) instead of building all three
+        const int rem = C & 3;
+        const bool last = c + 3 >= C;
+        v4f v{a.x, a.y, a.z, a.w};
+        int back = 0;
+        if (rem == 1) {
+            const float py = from_prev_lane(a.y), pz = from_prev_lane(a.z), pw = from_prev_lane(a.w);
+            if (last) v = v4f{py, pz, pw, a.x};
+            back = last ? 3 : 0;
+        } else if (rem == 2) {
+            const float pz = from_prev_lane(a.z), pw = from_prev_lane(a.w);
+            if (last) v = v4f{pz, pw, a.x, a.y};
+            back = last ? 2 : 0;
+        } else if (rem == 3) {
+            const float pw = from_prev_lane(a.w);
+            if (last) v = v4f{pw, a.x, a.y, a.z};
+            back = last ? 1 : 0;
+        }
+        store16(o - back, v, flavour & 7);
+        return;
+    }
     if (MERGE_TAIL) {
         const f4 p{from_prev_lane(a.x), from_prev_lane(a.y), from_prev_lane(a.z),
                    from_prev_lane(a.w)};
@@ -408,7 +432,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
         // a voxel is fetched into ONE XCD's L2 instead of all eight.
         // Bijective for any grid size (cdna_hip_programming.md, T1).
         const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = blk & 7;
-        blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blk >> 3);
+        if (P.xcd_rot == 0) {
+            blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blk >> 3);
+        } else {
+            // XCD x takes range (x + rot) & 7 of the order; a range has as many
+            // workgroups as its XCD receives (q or q + 1), so the map stays
+            // bijective for any grid size
+            const int mine = (xcd + P.xcd_rot) & 7;
+            int start = 0;
+            for (int r = 0; r < mine; ++r) start += q + ((((r - P.xcd_rot) & 7) < rr) ? 1 : 0);
+            blk = start + (blk >> 3);
+        }
     }
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPS;

@@ -24,6 +24,7 @@ Two flavours of the step loop are offered:
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -125,6 +126,8 @@ class TrackingEnvironment(BaseEnv):
         n = int(initial_points.shape[0])
         if n < 1:
             raise ValueError('need at least one seed')
+        if n >= self.VOLUME_TUNE_MIN_ROWS and self._sh_tuned is None:
+            self._tune_volume_placement(initial_points)
         self.initial_points = initial_points
         self._ensure_capacity(n)
         seeds32 = torch.from_numpy(
@@ -390,6 +393,22 @@ class TrackingEnvironment(BaseEnv):
                 and self.add_neighborhood_vox
                 and 0.0 < float(np.float32(self.add_neighborhood_vox)) < 1.0)
 
+    @staticmethod
+    def _wait_for_gpu(counts, step_no, timeout_s=20.0):
+        """Spin until the GPU has reported step ``step_no`` in the pinned words
+        (free-running loops: keeps the host a bounded number of steps ahead).
+        Bounded: a GPU that stopped answering surfaces as an error in
+        ``ttl_env_freerun_end`` instead of a hang here."""
+        if int(counts[2]) >= step_no:
+            return
+        t0 = time.perf_counter()
+        spins = 0
+        while int(counts[2]) < step_no:
+            spins += 1
+            if not spins & 0xfff and time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError('free-running step: no progress reported by the GPU '
+                                   f'for {timeout_s:.0f} s')
+
     def run_free_eager(self, policy, state, lookahead=2):
         """The same episode as ``run_free`` without a graph, for policies whose
         cost grows with the batch (the reference's default 1024-wide networks
@@ -411,6 +430,8 @@ class TrackingEnvironment(BaseEnv):
                 self._free_bufs = {}
             reward = torch.empty(n, dtype=torch.float64, device=dev) \
                 if self.compute_reward else None
+            if len(self._free_bufs) >= 4:       # batch sizes normally repeat
+                self._free_bufs.clear()
             buf = self._free_bufs[n] = (self._new_state(n),
                                         torch.empty(n, dtype=torch.uint8, device=dev), reward)
         state_buf, done, reward = buf
@@ -441,8 +462,7 @@ class TrackingEnvironment(BaseEnv):
                 if reward is not None:
                     reward_sum += reward[:cap].sum()
                 steps += 1
-                while steps - int(counts[2]) > lookahead:
-                    pass
+                self._wait_for_gpu(counts, steps - lookahead)
         finally:
             n_left, length, done_steps = C.c_int32(), C.c_int32(), C.c_int32()
             _lib.check(self._lib.ttl_env_freerun_end(
@@ -486,6 +506,8 @@ class TrackingEnvironment(BaseEnv):
         key = (n, id(policy) if key is None else key, bool(record_actions))
         fr = self._free_runs.get(key)
         if fr is None:          # buffers + one timing of the policy on n rows
+            if len(self._free_runs) >= 8:       # keys normally repeat (batch size, agent)
+                self._free_runs.clear()
             fr = self._free_runs[key] = _FreeRun(self, n, policy, record_actions)
         if max_policy_us is not None and fr.policy_us > max_policy_us:
             return None         # a replayed graph would lose to the shrinking batches
@@ -510,8 +532,8 @@ class TrackingEnvironment(BaseEnv):
                     break
                 # the host runs ahead of the GPU; keep the distance bounded so
                 # that few empty steps are queued behind the last real one
-                while steps - int(counts[2]) > 24 and counts[0] != 0:
-                    pass
+                if counts[0] != 0:
+                    self._wait_for_gpu(counts, steps - 24)
         finally:
             n_left, length, done = C.c_int32(), C.c_int32(), C.c_int32()
             _lib.check(self._lib.ttl_env_freerun_end(
@@ -566,6 +588,18 @@ class TrackingEnvironment(BaseEnv):
             self._idx_view(n).data_ptr(), n, int(seed) & 0xffffffff,
             int(step), float(wobble), out.data_ptr(), self._stream()),
             'ttl_scripted_actions')
+        return out
+
+    def scripted_actions_free(self, state, seed=0, wobble=0.05):
+        """``scripted_actions`` as the policy of a free-running episode
+        (``run_free_eager`` / ``run_free``): row count and step number are read
+        on the device; actions for ``len(state)`` rows."""
+        n = int(state.shape[0])
+        out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.ttl_env_freerun_scripted_actions(
+            self._handle, state.data_ptr(), state.stride(0), 7 * self._n_coef, n,
+            int(seed) & 0xffffffff, float(wobble), out.data_ptr(), self._stream()),
+            'ttl_env_freerun_scripted_actions')
         return out
 
     def profile_begin(self, max_launches=4096, classes=('state',)):
