@@ -201,3 +201,39 @@ def test_one_million_streamlines_sampled_against_the_oracle():
                           ref.streamlines[:, :L])                # bit-identical points
     assert np.array_equal(env.flags[sample], ref.flags)
     assert np.array_equal(env.lengths[sample], ref.lengths)
+
+
+def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch):
+    """The first reset of >= 65 536 streamlines on a volume of >= 64 MB re-rolls
+    where the packed SH volume lives (BaseEnv._tune_volume_placement: six
+    allocations, four real steps on each, the fastest kept).  It must leave no
+    trace but the address: the env's generator untouched (noise > 0), the state
+    and the first steps identical to an env that keeps its first allocation."""
+    N = 65536
+
+    def run(candidates):
+        monkeypatch.setenv('TTL_VOLUME_CANDIDATES', str(candidates))
+        env, _ = _make(96, N, 4, noisy=True, reward=False, max_length=60.0)
+        env.noise = 0.2
+        before = env.rng.get_state()[1].copy()
+        state = env.reset(0, N)
+        assert np.array_equal(env.rng.get_state()[1], before)      # nothing drawn yet
+        rows = [state.cpu().numpy()]
+        for step in range(3):
+            a = env.scripted_actions(state, step, seed=3, wobble=0.05)
+            env.step_device(a)
+            state, _ = env.harvest()
+            rows.append(state.cpu().numpy())
+        return env, rows
+
+    env_t, rows_t = run(6)
+    assert len(env_t._sh_tuned) == 6 and min(env_t._sh_tuned) > 0.0
+    assert env_t._sh_packed.data_ptr() == env_t._sh_memory.ptr
+    env_1, rows_1 = run(1)
+    assert env_1._sh_tuned == []
+    for a, b in zip(rows_t, rows_1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(env_t.rng.get_state()[1], env_1.rng.get_state()[1])
+    # a second large reset does not tune again
+    env_t.reset(0, N)
+    assert len(env_t._sh_tuned) == 6
