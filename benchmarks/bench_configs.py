@@ -86,5 +86,9 @@ def run(name, D, N, K, noisy, reward, max_length, steps=12, warmup=3,
 
 
 if __name__ == '__main__':
+    import os
+    extra = {}
+    if os.environ.get('BENCH_STEPS'):        # e.g. a window deeper into the episode
+        extra['steps'] = int(os.environ['BENCH_STEPS'])
     for name in (sys.argv[1:] or CONFIGS):
-        run(name, **CONFIGS[name])
+        run(name, **CONFIGS[name], **extra)
