@@ -102,9 +102,11 @@ class Tracker(object):
             env.initial_points, dtype=np.float64)).to(hist.device)[sel]
         return points, keep_sel, seeds
 
-    def _batch_items(self, env, scaled_min, scaled_max):
+    def _batch_items(self, env, scaled_min, scaled_max, transform=None):
         """(streamline, seed) pairs of the finished batch on this process;
-        with a process group, every rank's pairs, on rank 0 only."""
+        with a process group, every rank's pairs, on rank 0 only.
+        ``transform`` (packed (M, 3) points -> packed points) is applied to the
+        whole batch before it is cut into streamlines."""
         points, keep_sel, seeds = self._batch_arrays(env, scaled_min, scaled_max)
         if self.group_size > 1:
             # gather-to-root of exact sizes: only rank 0 consumes the tracts
@@ -117,6 +119,10 @@ class Tracker(object):
         points = points.cpu().numpy()
         keep_np = keep_sel.cpu().numpy()
         seeds = seeds.cpu().numpy()
+        if transform is not None:
+            # the whole batch at once: the same element-wise arithmetic as per
+            # streamline, a few numpy calls instead of a few per streamline
+            points = transform(points)
         offsets = np.concatenate(([0], np.cumsum(keep_np)))
         for k in range(len(keep_np)):
             yield points[offsets[k]:offsets[k + 1]], seeds[k]
@@ -150,13 +156,20 @@ class Tracker(object):
                     self.alg.validation_episode(state, env, self.prob)
                 else:           # an empty shard still joins the collectives
                     env._n_total = 0
+                # .trk without compression (ttl_track's default): the file-space
+                # conversion is element-wise, so it runs once over the packed
+                # batch -- bit for bit what the per-streamline call gives
+                whole_batch = tracts_format is TrkFile and not self.compress
                 for streamline, seed in self._batch_items(
-                        env, scaled_min_length, scaled_max_length):
+                        env, scaled_min_length, scaled_max_length,
+                        transform=(lambda p: to_file_space(p, TrkFile, affine, vox_size))
+                        if whole_batch else None):
                     if self.compress:
                         streamline = compress_streamline(
                             streamline, compress_th_vox)
-                    streamline = to_file_space(streamline, tracts_format,
-                                               affine, vox_size)
+                    if not whole_batch:
+                        streamline = to_file_space(streamline, tracts_format,
+                                                   affine, vox_size)
                     seed_dict = {}
                     if self.save_seeds:
                         seed_dict = {'seeds': seed - 0.5}
