@@ -45,6 +45,8 @@ def one(rng, k):
     os.environ['TTL_LOCAL_SORT'] = str(knobs.choice([0, 1]))
     os.environ['TTL_ORDER_KEY'] = str(knobs.choice([0, 1, 2, 3]))
     os.environ['TTL_ORDER_SORT'] = str(knobs.choice([0, 1]))
+    os.environ['TTL_STORE_FLAVOUR'] = str(knobs.choice([0, 8]))      # tail-merge variants
+    os.environ['TTL_XCD_ROTATE'] = str(knobs.randint(8))
     X, Y, Z = shape
     sh = (0.1 * rng.standard_normal((X, Y, Z, C))).astype(np.float32)
     g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing='ij'))
