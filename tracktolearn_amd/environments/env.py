@@ -309,8 +309,11 @@ class BaseEnv(object):
         try:
             for c in range(k):
                 if c > 0:
-                    mem = _lib.DeviceVolume(self._device_index, nbytes,
-                                            contiguous_ok and c % 2 == 1)
+                    try:
+                        mem = _lib.DeviceVolume(self._device_index, nbytes,
+                                                contiguous_ok and c % 2 == 1)
+                    except _lib.TTLError:
+                        break           # no room for another copy: keep the best so far
                     vol = torch.as_tensor(mem, device=self.device).view(torch.float32) \
                         .view(vol0.shape)
                     vol.copy_(vol0)
