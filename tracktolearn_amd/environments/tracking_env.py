@@ -409,6 +409,14 @@ class TrackingEnvironment(BaseEnv):
                 raise RuntimeError('free-running step: no progress reported by the GPU '
                                    f'for {timeout_s:.0f} s')
 
+    @staticmethod
+    def _no_grad():
+        # inference_mode skips autograd's view / version bookkeeping on top of
+        # no_grad (measurement knob: TTL_INFERENCE_MODE=0)
+        if os.environ.get('TTL_INFERENCE_MODE', '1') != '0':
+            return torch.inference_mode()
+        return torch.no_grad()
+
     def run_free_eager(self, policy, state, lookahead=2):
         """The same episode as ``run_free`` without a graph, for policies whose
         cost grows with the batch (the reference's default 1024-wide networks
@@ -453,7 +461,7 @@ class TrackingEnvironment(BaseEnv):
                 if c == 0:
                     break
                 cap = min(cap, c)
-                with torch.no_grad():
+                with self._no_grad():
                     a = policy(state_buf[:cap])
                 if a.dtype is not torch.float32 or not a.is_contiguous():
                     a = a.to(torch.float32).contiguous()
