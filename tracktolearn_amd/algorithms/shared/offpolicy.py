@@ -23,6 +23,30 @@ LOG_STD_MIN = -20
 _HALF_LOG_2PI = math.log(math.sqrt(2 * math.pi))
 
 
+def mlp_inference(layers, x):
+    """``layers(x)`` for a Linear / ReLU stack without autograd, with every
+    Linear + ReLU pair as ONE launch (the GEMM's ReLU epilogue,
+    ``torch._addmm_activation``: the same bits as ``relu(linear(x))`` on this
+    stack -- checked in tests -- and one launch less per hidden layer; a tracking
+    step at a few hundred rows is bound by its launches).  Anything else in the
+    stack, or a build without that entry point, takes the ordinary path."""
+    fused = getattr(torch, '_addmm_activation', None)
+    if fused is None or x.dim() != 2 or torch.is_grad_enabled():
+        return layers(x)
+    mods = list(layers)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear) and m.bias is not None and i + 1 < len(mods) \
+                and type(mods[i + 1]) is nn.ReLU:
+            x = fused(m.bias, x, m.weight.t(), use_gelu=False)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 class Actor(nn.Module):
     """Deterministic policy: state -> tanh(MLP(state)) (offpolicy.py:18-60)."""
 
@@ -68,7 +92,7 @@ class MaxEntropyActor(Actor):
         with the default networks a tracking step is bound by exactly those
         launches.  ``probabilistic == 0`` gives ``tanh(mu)`` (``eps * 0`` adds
         nothing) and draws no random numbers."""
-        p = self.layers(state)
+        p = mlp_inference(self.layers, state)
         mu = p[:, :self.action_dim]
         if not probabilistic:
             return self.output_activation(mu)
