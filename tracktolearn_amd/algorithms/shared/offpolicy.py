@@ -58,7 +58,7 @@ class Actor(nn.Module):
         self.output_activation = output_activation()
 
     def forward(self, state):
-        return self.output_activation(self.layers(state))
+        return self.output_activation(mlp_inference(self.layers, state))
 
 
 class MaxEntropyActor(Actor):
@@ -71,7 +71,7 @@ class MaxEntropyActor(Actor):
                                       action_dim * 2)
 
     def forward(self, state, probabilistic, eps=None):
-        p = self.layers(state)
+        p = mlp_inference(self.layers, state)
         mu = p[:, :self.action_dim]
         log_std = torch.clamp(p[:, self.action_dim:], LOG_STD_MIN, LOG_STD_MAX)
         std = torch.exp(log_std) * probabilistic
@@ -110,7 +110,7 @@ class Critic(nn.Module):
         self.q1 = make_fc_network(self.hidden_layers, state_dim + action_dim, 1)
 
     def forward(self, state, action):
-        return self.q1(torch.cat([state, action], -1)).squeeze(-1)
+        return mlp_inference(self.q1, torch.cat([state, action], -1)).squeeze(-1)
 
 
 class DoubleCritic(Critic):
@@ -124,10 +124,10 @@ class DoubleCritic(Critic):
 
     def forward(self, state, action):
         sa = torch.cat([state, action], -1)
-        return self.q1(sa).squeeze(-1), self.q2(sa).squeeze(-1)
+        return mlp_inference(self.q1, sa).squeeze(-1), mlp_inference(self.q2, sa).squeeze(-1)
 
     def Q1(self, state, action):
-        return self.q1(torch.cat([state, action], -1)).squeeze(-1)
+        return mlp_inference(self.q1, torch.cat([state, action], -1)).squeeze(-1)
 
 
 class ActorCritic(object):
