@@ -72,6 +72,27 @@ def main():
                       'us_scripted': timers[0] / steps * 1e6,
                       'us_step_device': timers[1] / steps * 1e6,
                       'us_harvest': timers[2] / steps * 1e6}), flush=True)
+    # the same episodes on free-running steps: scripted policy + step launched for
+    # the newest reported survivor count, the host never waiting for a step
+    for graph in (False, True):
+        policy = (lambda st: env.scripted_actions_free(st, 1, 0.05))
+        for _ in range(2):
+            state = env.reset(0, N)
+            (env.run_free(policy, state, key='scripted') if graph
+             else env.run_free_eager(policy, state))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fsteps = 0
+        for _ in range(5):
+            state = env.reset(0, N)
+            out = env.run_free(policy, state, key='scripted') if graph \
+                else env.run_free_eager(policy, state)
+            fsteps += out[1]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({'n_actor': N, 'loop': 'free-running, graphed' if graph
+                          else 'free-running, eager', 'steps': fsteps,
+                          'us_per_step': dt / fsteps * 1e6}), flush=True)
     pr = cProfile.Profile()
     pr.enable()
     episode(env, N)

@@ -513,16 +513,19 @@ class TrackingEnvironment(BaseEnv):
         n = self._n_active
         key = (n, id(policy) if key is None else key, bool(record_actions))
         fr = self._free_runs.get(key)
-        if fr is None:          # buffers + one timing of the policy on n rows
-            if len(self._free_runs) >= 8:       # keys normally repeat (batch size, agent)
-                self._free_runs.clear()
-            fr = self._free_runs[key] = _FreeRun(self, n, policy, record_actions)
-        if max_policy_us is not None and fr.policy_us > max_policy_us:
+        if fr is not None and max_policy_us is not None and fr.policy_us > max_policy_us:
             return None         # a replayed graph would lose to the shrinking batches
         _lib.check(self._lib.ttl_env_freerun_begin(
             self._handle, self._host_counts.data_ptr(), self._stream()),
             'ttl_env_freerun_begin')
         try:
+            if fr is None:      # buffers + one timing of the policy on n rows (the policy
+                # may itself read the free-running words: timed after begin)
+                if len(self._free_runs) >= 8:       # keys normally repeat (batch size, agent)
+                    self._free_runs.clear()
+                fr = self._free_runs[key] = _FreeRun(self, n, policy, record_actions)
+                if max_policy_us is not None and fr.policy_us > max_policy_us:
+                    return None
             if fr.graph is None:
                 fr.capture(self, policy)
             fr.state[:n].copy_(state)
