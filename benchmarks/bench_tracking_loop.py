@@ -67,6 +67,7 @@ def main():
     for name, flag, limit in (('step_by_step', '0', 0.0), ('free_running', '1', 0.0),
                               ('graphed', '1', 1e9)):
         os.environ['TTL_GRAPH_EPISODE'] = flag
+        os.environ['TTL_FREE_RUNNING_EAGER'] = '1'
         type(alg).graph_policy_us = limit     # 0: never the graph, 1e9: always
         run(env, alg, N, 2)                      # warm-up (and graph capture)
         dt, steps, units = run(env, alg, N, 5)

@@ -227,8 +227,9 @@ def test_free_running_steps_hand_the_episode_back():
 
 def test_expensive_policies_run_free_without_a_graph(monkeypatch):
     """run_free times the policy once on the full batch; above max_policy_us it
-    declines (None) and validation_episode launches policy + free-running step
-    itself, on batches that shrink with the reported survivor count."""
+    declines (None) and validation_episode keeps its step-by-step loop -- or,
+    with TTL_FREE_RUNNING_EAGER=1, launches policy + free-running step itself on
+    batches that shrink with the reported survivor count."""
     from tracktolearn_amd.algorithms.sac_auto import SACAuto
     N, K = 1200, 4
     env, _ = _env(20, N, K, noisy=True, reward=False)
@@ -237,11 +238,17 @@ def test_expensive_policies_run_free_without_a_graph(monkeypatch):
     monkeypatch.setattr(type(alg), 'graph_policy_us', 0.0)
     state = env.reset(0, N)
     assert alg._can_run_free(env)
-    alg.validation_episode(state, env, 0.0)
+    alg.validation_episode(state, env, 0.0)              # default: step by step
     assert env._n_active == 0 and env.length > 2
     (fr,) = env._free_runs.values()
     assert fr.graph is None and fr.policy_us > 0.0
-    assert list(env._free_bufs) == [N]          # the eager free-running loop ran
+    assert not env._free_bufs
+    lengths = env.lengths.copy()
+    monkeypatch.setenv('TTL_FREE_RUNNING_EAGER', '1')   # opt-in: never wait for a step
+    state = env.reset(0, N)
+    alg.validation_episode(state, env, 0.0)
+    assert list(env._free_bufs) == [N]
+    assert np.mean(env.lengths == lengths) >= 0.95
 
 
 def test_free_running_refuses_large_batches_and_noise():

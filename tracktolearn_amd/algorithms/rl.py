@@ -61,13 +61,20 @@ class RLAlgorithm(object):
                 lambda s: agent.select_action(s, probabilistic=prob), initial_state,
                 key=(id(agent), float(prob)),
                 max_policy_us=getattr(self, 'graph_policy_us', RLAlgorithm.graph_policy_us))
-            if out is None:
-                # the policy is too expensive to run on the full batch at every
-                # step: launch it on the newest reported survivor count instead,
-                # still without ever waiting for a step
+            if out is None and not prob and os.environ.get('TTL_FREE_RUNNING_EAGER', '0') == '1':
+                # Opt-in: the policy is too expensive to run on the full batch at
+                # every step, so launch it on the newest reported survivor count,
+                # still without ever waiting for a step (2-10 % faster than the
+                # loop below).  Not the default because how many rows a launch
+                # covers then depends on when the GPU reported its counts: a
+                # sampling policy would draw a different random stream from run
+                # to run, and even the deterministic one may round differently
+                # when the GEMM heuristics switch kernels with the row count --
+                # tractograms would not be reproducible bit for bit.
                 out = env.run_free_eager(
                     lambda s: agent.select_action(s, probabilistic=prob), initial_state)
-            return float(out[0]) if out[0] is not None else 0.0
+            if out is not None:
+                return float(out[0]) if out[0] is not None else 0.0
         running_reward = None
         state = initial_state
         while state.shape[0] > 0:
