@@ -33,6 +33,7 @@ def main():
     subject = bench.make_subject()
     env = bench.make_env(subject, 'cuda:0', 0)
     env.reset(0, bench.N_ACTOR)
+    env._state_ring = None          # this script places the state rows itself
     window(env)
     print(json.dumps(dict(default_ms=round(timed(env), 4))), flush=True)
     W = env._state_width

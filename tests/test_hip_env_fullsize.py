@@ -234,6 +234,25 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
     for a, b in zip(rows_t, rows_1):
         assert np.array_equal(a, b)
     assert np.array_equal(env_t.rng.get_state()[1], env_1.rng.get_state()[1])
+    # ... and the device-resident loop writes its state rows into a ring of
+    # four buffers in an allocation chosen the same way
+    assert len(env_t._ring_tuned) == 4 and len(env_t._state_ring) == 4
+    lo = env_t._state_ring_memory.ptr
+    hi = lo + env_t._state_ring_memory.nbytes
+    st = env_t.reset(0, N)
+    held, copies = [st], [st.cpu().numpy()]
+    for step in range(3):
+        a = env_t.scripted_actions(st, step, seed=3, wobble=0.05)
+        ns, _, _, _ = env_t.step_device(a)
+        assert lo <= ns.data_ptr() < hi
+        st, _ = env_t.harvest()
+        held.append(st)
+        copies.append(st.cpu().numpy())
+    # the tensors of the last three steps are intact (ring of four)
+    for got, want in zip(held, copies):
+        assert np.array_equal(got.cpu().numpy(), want)
+    ns, _, _, _ = env_t.step(env_t.scripted_actions(st, 3, seed=3, wobble=0.05).cpu().numpy())
+    assert not lo <= ns.data_ptr() < hi          # step() hands out fresh tensors
     # a second large reset does not tune again
     env_t.reset(0, N)
     assert len(env_t._sh_tuned) == 6

@@ -274,6 +274,8 @@ class BaseEnv(object):
             self.data_volume.data_ptr(), vol.data_ptr(), dims, n_coef, pitch,
             self._sh_layout, self._stream()), 'ttl_pack_sh_volume')
         self._sh_tuned = None          # candidate times once tuned
+        self._state_ring, self._state_ring_pos, self._state_ring_memory = None, 0, None
+        self._ring_tuned = None
         return vol, mem
 
     def _tune_volume_placement(self, seeds):
@@ -333,6 +335,8 @@ class BaseEnv(object):
                 self._sh_tuned.append(round(ms, 5))
                 if best is None or ms < best[0]:
                     best = (ms, c)
+            self._sh_packed, self._sh_memory = cands[best[1]]
+            self._tune_state_ring(seeds)
         finally:
             self._sh_packed, self._sh_memory = cands[best[1] if best else 0]
             self._destroy_handle()
@@ -340,6 +344,51 @@ class BaseEnv(object):
             self.initial_points = keep['initial_points']
             if keep['noise'] is not None:
                 self.noise = keep['noise']
+
+    def _tune_state_ring(self, seeds):
+        """The same measurement for the gather's OUTPUT.  State rows come from
+        the caching allocator, a fresh tensor per step; which block they land in
+        moves the gather by 5 % (0.203 against 0.193 ms on a box where every
+        placement of the volume was slow, ``benchmarks/placement_probe9.py``).
+        For the device-resident loop the host therefore keeps a ring of
+        STATE_RING state buffers in one allocation of its own and chooses that
+        allocation like the volume's: four candidates, four steps of the real
+        loop on each, the fastest kept."""
+        k = int(os.environ.get('TTL_STATE_RING_CANDIDATES', '4'))
+        ring_len = int(os.environ.get('TTL_STATE_RING', self.STATE_RING))
+        self._ring_tuned = []
+        if k < 1 or ring_len < 2:
+            return
+        n_ring = len(seeds)                     # the batch that triggered the tuning
+        n = min(n_ring, 131072)
+        self._destroy_handle()                  # the last volume candidate's handle
+        self._n_max = 0
+        row_bytes = self._state_pitch * 4
+        best = None
+        for c in range(k):
+            try:
+                mem = _lib.DeviceVolume(self._device_index, ring_len * n_ring * row_bytes, False)
+            except _lib.TTLError:
+                break
+            flat = torch.as_tensor(mem, device=self.device).view(torch.float32)
+            ring = [flat[i * n_ring * self._state_pitch:(i + 1) * n_ring * self._state_pitch]
+                    .view(n_ring, self._state_pitch)[:, :self._state_width]
+                    for i in range(ring_len)]
+            self._state_ring, self._state_ring_pos = ring, 0
+            state = self._start(seeds[:n])
+            self.profile_begin(16, classes=('state',))
+            for step in range(4):
+                if not self._n_active:
+                    break
+                self.step_device(self.scripted_actions(state, step, 1, 0.05))
+                state, _ = self.harvest()
+            total_ms, launches = self.profile_end()['state']
+            ms = total_ms / max(launches, 1)
+            self._ring_tuned.append(round(ms, 5))
+            if best is None or ms < best[0]:
+                best = (ms, ring, mem)
+        self._state_ring, self._state_ring_memory = (best[1], best[2]) if best else (None, None)
+        self._state_ring_pos = 0
 
     def _derive_tracking_params(self):
         """env.py:196-213: step size in voxels, step counts and the
@@ -376,6 +425,21 @@ class BaseEnv(object):
                                device=self.device)
         return torch.empty((n, self._state_pitch), dtype=torch.float32,
                            device=self.device)[:, :self._state_width]
+
+    #: state buffers of the device-resident loop (``step_device``) in memory
+    #: whose placement was measured: a ring of this many buffers, so that the
+    #: tensors of the last STATE_RING - 1 steps stay intact (TTL_STATE_RING=0:
+    #: a fresh ``torch.empty`` per step, as ``step()`` always does)
+    STATE_RING = 4
+
+    def _ring_state(self, n):
+        """State rows for a reset / ``step_device``: the next buffer of the placed
+        ring when there is one that fits, a fresh tensor otherwise."""
+        ring = self._state_ring
+        if ring is None or n > ring[0].shape[0]:
+            return self._new_state(n)
+        self._state_ring_pos = (self._state_ring_pos + 1) % len(ring)
+        return ring[self._state_ring_pos][:n]
 
     def _stream(self):
         """Raw HIP stream torch currently launches on for this device (the

@@ -133,7 +133,7 @@ class TrackingEnvironment(BaseEnv):
         seeds32 = torch.from_numpy(
             np.ascontiguousarray(initial_points, dtype=np.float32)
         ).to(self.device)
-        state = self._new_state(n)
+        state = self._ring_state(n)
         # batches of SPATIAL_ORDER_MIN rows and more are gathered in a
         # spatially sorted processing order (built by the library)
         sort_rows = n >= self.SPATIAL_ORDER_MIN and getattr(self, 'spatial_order', True)
@@ -215,7 +215,9 @@ class TrackingEnvironment(BaseEnv):
         a = self._actions_to_device(actions)
         noise = self._noise_for(a)
         self._refresh_processing_order()
-        state = self._new_state(n)
+        # the device-resident loop writes into the placed ring (env.py); step()
+        # hands out fresh tensors as the reference does
+        state = self._ring_state(n) if order == _lib.ORDER_PARTITION else self._new_state(n)
         done = torch.empty(n, dtype=torch.uint8, device=self.device)
         reward = None
         if self.compute_reward:
