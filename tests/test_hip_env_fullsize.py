@@ -236,7 +236,7 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
     assert np.array_equal(env_t.rng.get_state()[1], env_1.rng.get_state()[1])
     # ... and the device-resident loop writes its state rows into a ring of
     # four buffers in an allocation chosen the same way
-    assert len(env_t._ring_tuned) == 4 and len(env_t._state_ring) == 4
+    assert len(env_t._ring_tuned) == 6 and len(env_t._state_ring) == 4
     lo = env_t._state_ring_memory.ptr
     hi = lo + env_t._state_ring_memory.nbytes
     st = env_t.reset(0, N)

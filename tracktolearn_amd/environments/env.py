@@ -352,9 +352,11 @@ class BaseEnv(object):
         placement of the volume was slow, ``benchmarks/placement_probe9.py``).
         For the device-resident loop the host therefore keeps a ring of
         STATE_RING state buffers in one allocation of its own and chooses that
-        allocation like the volume's: four candidates, four steps of the real
-        loop on each, the fastest kept."""
-        k = int(os.environ.get('TTL_STATE_RING_CANDIDATES', '4'))
+        allocation like the volume's: six candidates, four steps of the real
+        loop on each, the fastest kept.  (The allocator's own blocks are not a
+        candidate: which block a step gets changes with the pool's history and
+        with the batch size, so a measurement of them predicts nothing.)"""
+        k = int(os.environ.get('TTL_STATE_RING_CANDIDATES', '6'))
         ring_len = int(os.environ.get('TTL_STATE_RING', self.STATE_RING))
         self._ring_tuned = []
         if k < 1 or ring_len < 2:
