@@ -537,12 +537,10 @@ def main(argv=None):
         if ep is not None:
             line['whole_episode'] = ep
         if getattr(env, '_sh_tuned', None):
-            # gather time of every candidate placement of the SH volume (ms per launch at
-            # 131 072 streamlines); the fastest was kept (env.py:_tune_volume_placement)
-            line['volume_placement_candidates_ms'] = env._sh_tuned
-        if getattr(env, '_ring_tuned', None):
-            # the same for the allocation that holds the ring of state buffers
-            line['state_ring_candidates_ms'] = env._ring_tuned
+            # gather time (ms per launch at 131 072 streamlines) of every pair
+            # (allocation of the SH volume, allocation of the state ring) tried at the
+            # first large reset; the fastest pair was kept (env.py:_tune_placement)
+            line['placement_candidates_ms'] = env._sh_tuned
         if collate_ms is not None:
             line['collate_ms'] = collate_ms
             line['collate_bytes_to_root'] = collate_bytes

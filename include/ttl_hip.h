@@ -148,9 +148,10 @@ int64_t ttl_sh_volume_records(const int32_t *dim /*[3]*/, int32_t layout);
  * current device.  These two entry points are the only ones that own device
  * memory; everything else is borrowed.  They exist because WHERE the 170 MB
  * volume of the bench lands in physical memory moves the state gather between
- * 0.18 and 0.20 ms on the same GPU: the host classes pack a
- * subject's volume into a few allocations obtained here, time the step's own
- * gather on each at the first large reset and keep the fastest; the caching
+ * 0.18 and 0.20 ms on the same GPU, and so does where the state rows land
+ * (DESIGN.md 3.3): the host classes put a subject's volume and a ring of state
+ * buffers into a few allocations obtained here, time the step's own gather on
+ * every pair at the first large reset and keep the fastest; the caching
  * allocator would hand the same block back every time. */
 int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void **out,
                      int32_t *contiguous_out);

@@ -205,8 +205,9 @@ def test_one_million_streamlines_sampled_against_the_oracle():
 
 def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch):
     """The first reset of >= 65 536 streamlines on a volume of >= 64 MB re-rolls
-    where the packed SH volume lives (BaseEnv._tune_volume_placement: six
-    allocations, four real steps on each, the fastest kept).  It must leave no
+    where the packed SH volume and the ring of state buffers live
+    (BaseEnv._tune_placement: four allocations of each, four real steps on
+    every pair, the fastest pair kept).  It must leave no
     trace but the address: the env's generator untouched (noise > 0), the state
     and the first steps identical to an env that keeps its first allocation."""
     N = 65536
@@ -226,8 +227,8 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
             rows.append(state.cpu().numpy())
         return env, rows
 
-    env_t, rows_t = run(6)
-    assert len(env_t._sh_tuned) == 6 and min(env_t._sh_tuned) > 0.0
+    env_t, rows_t = run(4)
+    assert len(env_t._sh_tuned) == 4 and all(len(r) == 4 and min(r) > 0.0 for r in env_t._sh_tuned)
     assert env_t._sh_packed.data_ptr() == env_t._sh_memory.ptr
     env_1, rows_1 = run(1)
     assert env_1._sh_tuned == []
@@ -236,7 +237,7 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
     assert np.array_equal(env_t.rng.get_state()[1], env_1.rng.get_state()[1])
     # ... and the device-resident loop writes its state rows into a ring of
     # four buffers in an allocation chosen the same way
-    assert len(env_t._ring_tuned) == 6 and len(env_t._state_ring) == 4
+    assert len(env_t._state_ring) == 4
     lo = env_t._state_ring_memory.ptr
     hi = lo + env_t._state_ring_memory.nbytes
     st = env_t.reset(0, N)
@@ -255,4 +256,4 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
     assert not lo <= ns.data_ptr() < hi          # step() hands out fresh tensors
     # a second large reset does not tune again
     env_t.reset(0, N)
-    assert len(env_t._sh_tuned) == 6
+    assert len(env_t._sh_tuned) == 4

@@ -255,9 +255,12 @@ class BaseEnv(object):
         return (float(self.step_size_mm), float(self.min_length_mm),
                 float(self.max_length_mm))
 
-    #: candidate placements of the packed SH volume tried at the first large
-    #: reset (TTL_VOLUME_CANDIDATES; 1 = keep the first allocation)
-    VOLUME_CANDIDATES = 6
+    #: placements tried at the first large reset: this many allocations of the
+    #: packed SH volume x this many allocations of the state ring
+    #: (TTL_VOLUME_CANDIDATES, TTL_STATE_RING_CANDIDATES; 1 and 0 = keep the first
+    #: allocation of the volume and fresh state tensors per step)
+    VOLUME_CANDIDATES = 4
+    STATE_RING_CANDIDATES = 4
     #: volumes below this sit in the caches wherever they are
     VOLUME_TUNE_MIN_BYTES = 64 << 20
     #: batches below this are bound by launches, not by the gather
@@ -265,132 +268,109 @@ class BaseEnv(object):
 
     def _place_sh_volume(self, dims, n_coef, pitch, n_rec, mask_data):
         """Pack the SH volume into device memory of its own (``ttl_volume_alloc``,
-        not the caching allocator: ``_tune_volume_placement`` may want to
-        re-roll where it lands).  Returns ``(tensor (n_rec, pitch) float32,
-        owner of its memory)``."""
+        not the caching allocator: ``_tune_placement`` may want to re-roll where
+        it lands).  Returns ``(tensor (n_rec, pitch) float32, owner of its
+        memory)``."""
         mem = _lib.DeviceVolume(self._device_index, n_rec * pitch * 4, False)
         vol = torch.as_tensor(mem, device=self.device).view(torch.float32).view(n_rec, pitch)
         _lib.check(self._lib.ttl_pack_sh_volume(
             self.data_volume.data_ptr(), vol.data_ptr(), dims, n_coef, pitch,
             self._sh_layout, self._stream()), 'ttl_pack_sh_volume')
-        self._sh_tuned = None          # candidate times once tuned
+        self._sh_tuned = None          # the matrix of candidate times once tuned
         self._state_ring, self._state_ring_pos, self._state_ring_memory = None, 0, None
-        self._ring_tuned = None
         return vol, mem
 
-    def _tune_volume_placement(self, seeds):
-        """Where the 170 MB volume of the bench lands in physical memory moves
-        the state gather between 0.18 and 0.20 ms on the same GPU: exchanging
-        nothing but this buffer between two env instances exchanges their times,
-        the counters show the same requests at a longer memory-side read
-        latency, and nothing visible from user space predicts it (address,
-        contiguity, which XCD reads which part; ``benchmarks/placement_probe*.py``,
+    def _tune_placement(self, seeds):
+        """Where the gather's source (the 170 MB packed SH volume of the bench)
+        and its destination (the state rows) land in device memory moves the
+        kernel between 0.18 and 0.20 ms on the same GPU -- as a PAIR: with five
+        allocations of each, volumes fall into two classes and so do the
+        allocations of the rows, one combination is the fastest (0.1805 ms), the
+        same volume with the other class of rows the slowest (0.197), the other
+        volumes sit in between with either (0.187-0.189)
+        (``benchmarks/placement_probe13.py``; the counters show the same
+        requests at a longer memory-side latency; address, alignment,
+        contiguity, which XCD reads what: none of it predicts the class --
         DESIGN.md 3.3).  So the host measures, once per subject, at the first
         reset of at least VOLUME_TUNE_MIN_ROWS streamlines: the volume is copied
-        into VOLUME_CANDIDATES allocations (every other one physically
-        contiguous when the driver grants it), each runs four steps of the real
-        loop on up to 131 072 of the given seeds with the scripted policy, and
-        the allocation with the fastest gather is kept.  Costs ~30 ms; changes
-        no result (the same bytes at another address)."""
-        k = int(os.environ.get('TTL_VOLUME_CANDIDATES', self.VOLUME_CANDIDATES))
+        into VOLUME_CANDIDATES allocations, a ring of STATE_RING state buffers
+        (for the device-resident loop) is laid out in STATE_RING_CANDIDATES
+        allocations, every pair runs four steps of the real loop on up to
+        131 072 of the given seeds with the scripted policy, and the pair with
+        the fastest gather is kept (16 pairs, ~80 ms; the same bytes at other
+        addresses: no result changes).  The caching allocator's own blocks are
+        no candidate for the rows: which block a step gets changes with the
+        pool's history and with the batch size."""
+        kv = int(os.environ.get('TTL_VOLUME_CANDIDATES', self.VOLUME_CANDIDATES))
+        kr = int(os.environ.get('TTL_STATE_RING_CANDIDATES', self.STATE_RING_CANDIDATES))
+        ring_len = int(os.environ.get('TTL_STATE_RING', self.STATE_RING))
         vol0, mem0 = self._sh_packed, self._sh_memory
         nbytes = vol0.numel() * 4
         radius = float(np.float32(self.add_neighborhood_vox or 0.0))
         self._sh_tuned = []
-        if k < 2 or nbytes < self.VOLUME_TUNE_MIN_BYTES or not 0.0 < radius < 1.0 \
+        if kv < 2 or nbytes < self.VOLUME_TUNE_MIN_BYTES or not 0.0 < radius < 1.0 \
                 or self._use_oracle_stopping or self._use_oracle_reward:
             return
-        contiguous_ok = os.environ.get('TTL_CONTIGUOUS_VOLUME', '1') != '0'
-        n = min(len(seeds), 131072)
+        if ring_len < 2:
+            kr = 0
+        n_ring = len(seeds)                     # the batch that triggered the tuning
+        n = min(n_ring, 131072)
         keep = dict(initial_points=getattr(self, 'initial_points', None),
                     noise=getattr(self, 'noise', None))
         if keep['noise'] is not None:
             self.noise = 0.0           # the probe steps must not draw from the env's generator
+        vols, rings = [(vol0, mem0)], []
         best = None
-        cands = [(vol0, mem0)]
         try:
-            for c in range(k):
-                if c > 0:
-                    try:
-                        mem = _lib.DeviceVolume(self._device_index, nbytes,
-                                                contiguous_ok and c % 2 == 1)
-                    except _lib.TTLError:
-                        break           # no room for another copy: keep the best so far
-                    vol = torch.as_tensor(mem, device=self.device).view(torch.float32) \
-                        .view(vol0.shape)
-                    vol.copy_(vol0)
-                    cands.append((vol, mem))
-                self._sh_packed, self._sh_memory = cands[c]
+            for c in range(1, kv):
+                try:
+                    mem = _lib.DeviceVolume(self._device_index, nbytes, False)
+                except _lib.TTLError:
+                    break               # no room for another copy
+                vol = torch.as_tensor(mem, device=self.device).view(torch.float32) \
+                    .view(vol0.shape)
+                vol.copy_(vol0)
+                vols.append((vol, mem))
+            pitch, width = self._state_pitch, self._state_width
+            for c in range(kr):
+                try:
+                    mem = _lib.DeviceVolume(self._device_index, ring_len * n_ring * pitch * 4,
+                                            False)
+                except _lib.TTLError:
+                    break
+                flat = torch.as_tensor(mem, device=self.device).view(torch.float32)
+                rings.append(([flat[i * n_ring * pitch:(i + 1) * n_ring * pitch]
+                               .view(n_ring, pitch)[:, :width] for i in range(ring_len)], mem))
+            for vi, (vol, mem) in enumerate(vols):
+                self._sh_packed, self._sh_memory = vol, mem
                 self._destroy_handle()
                 self._n_max = 0
-                state = self._start(seeds[:n])
-                self.profile_begin(16, classes=('state',))
-                for step in range(4):
-                    if not self._n_active:
-                        break
-                    self.step_device(self.scripted_actions(state, step, 1, 0.05))
-                    state, _ = self.harvest()
-                total_ms, launches = self.profile_end()['state']
-                ms = total_ms / max(launches, 1)
-                self._sh_tuned.append(round(ms, 5))
-                if best is None or ms < best[0]:
-                    best = (ms, c)
-            self._sh_packed, self._sh_memory = cands[best[1]]
-            self._tune_state_ring(seeds)
+                row = []
+                for ri, (ring, rmem) in enumerate(rings or [(None, None)]):
+                    self._state_ring, self._state_ring_pos = ring, 0
+                    state = self._start(seeds[:n])
+                    self.profile_begin(16, classes=('state',))
+                    for step in range(4):
+                        if not self._n_active:
+                            break
+                        self.step_device(self.scripted_actions(state, step, 1, 0.05))
+                        state, _ = self.harvest()
+                    total_ms, launches = self.profile_end()['state']
+                    ms = total_ms / max(launches, 1)
+                    row.append(round(ms, 5))
+                    if best is None or ms < best[0]:
+                        best = (ms, vi, ri)
+                self._sh_tuned.append(row)
         finally:
-            self._sh_packed, self._sh_memory = cands[best[1] if best else 0]
+            vi, ri = (best[1], best[2]) if best else (0, 0)
+            self._sh_packed, self._sh_memory = vols[vi]
+            self._state_ring, self._state_ring_memory = rings[ri] if rings else (None, None)
+            self._state_ring_pos = 0
             self._destroy_handle()
             self._n_max = 0
             self.initial_points = keep['initial_points']
             if keep['noise'] is not None:
                 self.noise = keep['noise']
-
-    def _tune_state_ring(self, seeds):
-        """The same measurement for the gather's OUTPUT.  State rows come from
-        the caching allocator, a fresh tensor per step; which block they land in
-        moves the gather by 5 % (0.203 against 0.193 ms on a box where every
-        placement of the volume was slow, ``benchmarks/placement_probe9.py``).
-        For the device-resident loop the host therefore keeps a ring of
-        STATE_RING state buffers in one allocation of its own and chooses that
-        allocation like the volume's: six candidates, four steps of the real
-        loop on each, the fastest kept.  (The allocator's own blocks are not a
-        candidate: which block a step gets changes with the pool's history and
-        with the batch size, so a measurement of them predicts nothing.)"""
-        k = int(os.environ.get('TTL_STATE_RING_CANDIDATES', '6'))
-        ring_len = int(os.environ.get('TTL_STATE_RING', self.STATE_RING))
-        self._ring_tuned = []
-        if k < 1 or ring_len < 2:
-            return
-        n_ring = len(seeds)                     # the batch that triggered the tuning
-        n = min(n_ring, 131072)
-        self._destroy_handle()                  # the last volume candidate's handle
-        self._n_max = 0
-        row_bytes = self._state_pitch * 4
-        best = None
-        for c in range(k):
-            try:
-                mem = _lib.DeviceVolume(self._device_index, ring_len * n_ring * row_bytes, False)
-            except _lib.TTLError:
-                break
-            flat = torch.as_tensor(mem, device=self.device).view(torch.float32)
-            ring = [flat[i * n_ring * self._state_pitch:(i + 1) * n_ring * self._state_pitch]
-                    .view(n_ring, self._state_pitch)[:, :self._state_width]
-                    for i in range(ring_len)]
-            self._state_ring, self._state_ring_pos = ring, 0
-            state = self._start(seeds[:n])
-            self.profile_begin(16, classes=('state',))
-            for step in range(4):
-                if not self._n_active:
-                    break
-                self.step_device(self.scripted_actions(state, step, 1, 0.05))
-                state, _ = self.harvest()
-            total_ms, launches = self.profile_end()['state']
-            ms = total_ms / max(launches, 1)
-            self._ring_tuned.append(round(ms, 5))
-            if best is None or ms < best[0]:
-                best = (ms, ring, mem)
-        self._state_ring, self._state_ring_memory = (best[1], best[2]) if best else (None, None)
-        self._state_ring_pos = 0
 
     def _derive_tracking_params(self):
         """env.py:196-213: step size in voxels, step counts and the

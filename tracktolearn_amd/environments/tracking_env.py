@@ -127,7 +127,7 @@ class TrackingEnvironment(BaseEnv):
         if n < 1:
             raise ValueError('need at least one seed')
         if n >= self.VOLUME_TUNE_MIN_ROWS and self._sh_tuned is None:
-            self._tune_volume_placement(initial_points)
+            self._tune_placement(initial_points)
         self.initial_points = initial_points
         self._ensure_capacity(n)
         seeds32 = torch.from_numpy(
