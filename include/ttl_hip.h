@@ -142,9 +142,12 @@ size_t ttl_env_workspace_bytes(int32_t n_max);
 int64_t ttl_sh_volume_records(const int32_t *dim /*[3]*/, int32_t layout);
 
 /* Device memory for a volume the step gathers from (the packed SH volume):
- * with try_contiguous physically contiguous (hipExtMallocWithFlags,
- * hipDeviceMallocContiguous) when the driver grants it, plain hipMalloc
- * otherwise; *contiguous_out says which.  device < 0: the calling thread's
+ * try_contiguous 0: plain hipMalloc; 1: physically contiguous
+ * (hipExtMallocWithFlags, hipDeviceMallocContiguous) when the driver grants it;
+ * 2: through the virtual-memory API (hipMemCreate + hipMemMap at the
+ * recommended granularity), hipMalloc when that fails; *contiguous_out says
+ * which was granted (measurement showed no kind to be better placed than
+ * another; the host classes use 0).  device < 0: the calling thread's
  * current device.  These two entry points are the only ones that own device
  * memory; everything else is borrowed.  They exist because WHERE the 170 MB
  * volume of the bench lands in physical memory moves the state gather between

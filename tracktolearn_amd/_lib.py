@@ -171,9 +171,9 @@ class DeviceVolume:
     def __init__(self, device_index, nbytes, try_contiguous=False):
         lib = load()
         ptr, contiguous = C.c_void_p(), C.c_int32()
-        check(lib.ttl_volume_alloc(int(device_index), int(nbytes), 1 if try_contiguous else 0,
+        check(lib.ttl_volume_alloc(int(device_index), int(nbytes), int(try_contiguous),
                                    C.byref(ptr), C.byref(contiguous)), 'ttl_volume_alloc')
-        self.ptr, self.nbytes, self.contiguous = ptr.value, int(nbytes), bool(contiguous.value)
+        self.ptr, self.nbytes, self.contiguous = ptr.value, int(nbytes), int(contiguous.value)
         self.__cuda_array_interface__ = {'shape': (self.nbytes,), 'typestr': '|u1',
                                          'data': (self.ptr, False), 'version': 2}
 

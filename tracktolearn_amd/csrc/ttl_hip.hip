@@ -35,6 +35,9 @@
 
 #include "ttl_internal.h"
 
+#include <map>
+#include <mutex>
+
 namespace {
 thread_local char g_err[512] = "";
 }
@@ -955,6 +958,49 @@ int64_t ttl_sh_volume_records(const int32_t *dim, int32_t layout) {
 
 // Device memory for a gathered volume: on request physically contiguous when
 // the driver can give that, ordinary hipMalloc otherwise.
+// allocations made through the virtual-memory API (try_contiguous == 2): what
+// ttl_volume_free needs to undo them
+struct VmmBlock {
+    hipMemGenericAllocationHandle_t handle;
+    size_t size;
+};
+static std::mutex g_vmm_mutex;
+static std::map<void *, VmmBlock> g_vmm_blocks;
+
+static hipError_t vmm_alloc(int device, size_t bytes, void **out) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop,
+                                                  hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess || gran == 0) return e != hipSuccess ? e : hipErrorInvalidValue;
+    const size_t size = (bytes + gran - 1) / gran * gran;
+    VmmBlock b{};
+    b.size = size;
+    if ((e = hipMemCreate(&b.handle, size, &prop, 0)) != hipSuccess) return e;
+    void *va = nullptr;
+    if ((e = hipMemAddressReserve(&va, size, gran, nullptr, 0)) != hipSuccess) {
+        (void)hipMemRelease(b.handle);
+        return e;
+    }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemMap(va, size, 0, b.handle, 0)) != hipSuccess ||
+        (e = hipMemSetAccess(va, size, &acc, 1)) != hipSuccess) {
+        (void)hipMemUnmap(va, size);
+        (void)hipMemAddressFree(va, size);
+        (void)hipMemRelease(b.handle);
+        return e;
+    }
+    std::lock_guard<std::mutex> lock(g_vmm_mutex);
+    g_vmm_blocks[va] = b;
+    *out = va;
+    return hipSuccess;
+}
+
 int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void **out,
                      int32_t *contiguous_out) {
     if (!out || bytes == 0) return fail(TTL_ERR_INVALID, "ttl_volume_alloc: bad arguments");
@@ -963,7 +1009,14 @@ int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void 
     if (device >= 0 && device != prev) HIP_TRY(hipSetDevice(device));
     void *p = nullptr;
     int contiguous = 0;
-    if (try_contiguous) {
+    if (try_contiguous == 2) {          // experiment: the virtual-memory API
+        if (vmm_alloc(device >= 0 ? device : prev, bytes, &p) == hipSuccess && p)
+            contiguous = 2;
+        else {
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+    } else if (try_contiguous) {
         if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) == hipSuccess && p)
             contiguous = 1;
         else {
@@ -981,7 +1034,22 @@ int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void 
 }
 
 int ttl_volume_free(void *ptr) {
-    if (ptr) HIP_TRY(hipFree(ptr));
+    if (!ptr) return TTL_OK;
+    {
+        std::unique_lock<std::mutex> lock(g_vmm_mutex);
+        auto it = g_vmm_blocks.find(ptr);
+        if (it != g_vmm_blocks.end()) {
+            const VmmBlock b = it->second;
+            g_vmm_blocks.erase(it);
+            lock.unlock();
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemUnmap(ptr, b.size));
+            HIP_TRY(hipMemAddressFree(ptr, b.size));
+            HIP_TRY(hipMemRelease(b.handle));
+            return TTL_OK;
+        }
+    }
+    HIP_TRY(hipFree(ptr));
     return TTL_OK;
 }
 

@@ -259,8 +259,8 @@ class BaseEnv(object):
     #: packed SH volume x this many allocations of the state ring
     #: (TTL_VOLUME_CANDIDATES, TTL_STATE_RING_CANDIDATES; 1 and 0 = keep the first
     #: allocation of the volume and fresh state tensors per step)
-    VOLUME_CANDIDATES = 4
-    STATE_RING_CANDIDATES = 4
+    VOLUME_CANDIDATES = 3
+    STATE_RING_CANDIDATES = 8
     #: volumes below this sit in the caches wherever they are
     VOLUME_TUNE_MIN_BYTES = 64 << 20
     #: batches below this are bound by launches, not by the gather
@@ -297,7 +297,7 @@ class BaseEnv(object):
         (for the device-resident loop) is laid out in STATE_RING_CANDIDATES
         allocations, every pair runs four steps of the real loop on up to
         131 072 of the given seeds with the scripted policy, and the pair with
-        the fastest gather is kept (16 pairs, ~80 ms; the same bytes at other
+        the fastest gather is kept (24 pairs, ~100 ms; the same bytes at other
         addresses: no result changes).  The caching allocator's own blocks are
         no candidate for the rows: which block a step gets changes with the
         pool's history and with the batch size."""
