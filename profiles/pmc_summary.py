@@ -46,6 +46,33 @@ def counters(dirname, counter):
     return rows
 
 
+def durations_by_size(stats_dir):
+    """Average duration of the state gather per launch size, from the kernel
+    trace of the --stats pass: the aggregated stats mix the step launches of the
+    timed windows (all rows active) with the placement search's launches on
+    131 072 rows (env.py:_tune_placement), which pulls their average down."""
+    paths = glob.glob(os.path.join(stats_dir, '**', '*_kernel_trace.csv'), recursive=True)
+    if not paths:
+        return []
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(paths[0])):
+        k = short(r['Kernel_Name'])
+        if not k.startswith('k_state'):
+            continue
+        grid = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
+        m = re.match(r'k_state(?:_dd)?<(\d+)', k)
+        units = grid // 256 * (4 * (64 // int(m.group(1))) if m else 20)
+        dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3      # us
+        groups[(k, 'more than 200 000 rows (steps and resets of the windows)' if units > 200000
+                else 'at most 200 000 rows (placement search, warm-up tail)')].append((dur, units))
+    out = ['state gather by launch size, rocprofv3 kernel trace of the --stats pass:']
+    for (k, what), rows in sorted(groups.items()):
+        out.append(f'{k} | {what} | {len(rows)} launches | '
+                   f'{sum(u for _, u in rows) / len(rows):.0f} rows avg | '
+                   f'{sum(d for d, _ in rows) / len(rows):.1f} us avg')
+    return out
+
+
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
     json_name = sys.argv[5] if len(sys.argv) > 5 else 'pmc_traffic.json'
@@ -86,6 +113,7 @@ def main():
         lines.append(f'{k}: {js["k_state_units_per_launch"]:.0f} units/launch (from '
                      f'the grid sizes) -> {js["k_state_hbm_bytes_per_unit"]:.1f} HBM '
                      f'bytes per unit')
+    lines += durations_by_size(stats_dir)
     open(os.path.join(HERE, f'{tag}_pmc_traffic.txt'), 'w').write(
         '\n'.join(lines) + '\n')
     json.dump(js, open(os.path.join(HERE, json_name), 'w'), indent=1)
