@@ -260,7 +260,9 @@ class BaseEnv(object):
     #: (TTL_VOLUME_CANDIDATES, TTL_STATE_RING_CANDIDATES; 1 and 0 = keep the first
     #: allocation of the volume and fresh state tensors per step)
     VOLUME_CANDIDATES = 3
-    STATE_RING_CANDIDATES = 8
+    STATE_RING_CANDIDATES = 16
+    #: device memory the ring candidates may hold together during the search
+    STATE_RING_SEARCH_BYTES = 32 << 30
     #: volumes below this sit in the caches wherever they are
     VOLUME_TUNE_MIN_BYTES = 64 << 20
     #: batches below this are bound by launches, not by the gather
@@ -293,14 +295,15 @@ class BaseEnv(object):
         contiguity, which XCD reads what: none of it predicts the class --
         DESIGN.md 3.3).  So the host measures, once per subject, at the first
         reset of at least VOLUME_TUNE_MIN_ROWS streamlines: the volume is copied
-        into VOLUME_CANDIDATES allocations, a ring of STATE_RING state buffers
-        (for the device-resident loop) is laid out in STATE_RING_CANDIDATES
-        allocations, every pair runs four steps of the real loop on up to
-        131 072 of the given seeds with the scripted policy, and the pair with
-        the fastest gather is kept (24 pairs, ~100 ms; the same bytes at other
-        addresses: no result changes).  The caching allocator's own blocks are
-        no candidate for the rows: which block a step gets changes with the
-        pool's history and with the batch size."""
+        into VOLUME_CANDIDATES allocations, STATE_RING_CANDIDATES state buffers
+        (for the device-resident loop) are allocated one by one, every pair
+        (volume, buffer) runs four steps of the real loop on up to
+        262 144 of the given seeds with the scripted policy, and the pair with
+        the fastest gather wins (51 pairs, ~0.3 s; the same bytes at other
+        addresses: no result changes): its volume is kept, and the STATE_RING
+        buffers that were fastest with that volume form the ring.  The caching
+        allocator's own blocks (no ring: a fresh state tensor per step) are the
+        17th candidate for the rows when the probe runs at the batch's own size."""
         kv = int(os.environ.get('TTL_VOLUME_CANDIDATES', self.VOLUME_CANDIDATES))
         kr = int(os.environ.get('TTL_STATE_RING_CANDIDATES', self.STATE_RING_CANDIDATES))
         ring_len = int(os.environ.get('TTL_STATE_RING', self.STATE_RING))
@@ -314,12 +317,15 @@ class BaseEnv(object):
         if ring_len < 2:
             kr = 0
         n_ring = len(seeds)                     # the batch that triggered the tuning
-        n = min(n_ring, 131072)
+        n = min(n_ring, 262144)
+        buf_bytes = n_ring * self._state_pitch * 4
+        if kr > 0:
+            kr = max(ring_len, min(kr, self.STATE_RING_SEARCH_BYTES // max(buf_bytes, 1)))
         keep = dict(initial_points=getattr(self, 'initial_points', None),
                     noise=getattr(self, 'noise', None))
         if keep['noise'] is not None:
             self.noise = 0.0           # the probe steps must not draw from the env's generator
-        vols, rings = [(vol0, mem0)], []
+        vols, rings, candidates = [(vol0, mem0)], [], [(None, None)]
         best = None
         try:
             for c in range(1, kv):
@@ -332,21 +338,25 @@ class BaseEnv(object):
                 vol.copy_(vol0)
                 vols.append((vol, mem))
             pitch, width = self._state_pitch, self._state_width
-            for c in range(kr):
+            for c in range(kr):     # state buffers, one allocation each
                 try:
-                    mem = _lib.DeviceVolume(self._device_index, ring_len * n_ring * pitch * 4,
-                                            False)
+                    mem = _lib.DeviceVolume(self._device_index, buf_bytes, False)
                 except _lib.TTLError:
                     break
                 flat = torch.as_tensor(mem, device=self.device).view(torch.float32)
-                rings.append(([flat[i * n_ring * pitch:(i + 1) * n_ring * pitch]
-                               .view(n_ring, pitch)[:, :width] for i in range(ring_len)], mem))
+                rings.append(([flat.view(n_ring, pitch)[:, :width]], mem))
+            if len(rings) < ring_len:
+                rings = []
+            # the caching allocator's own blocks (fresh state tensors per step, as
+            # without a ring) compete too when the probe runs at the batch's own
+            # size: a step then gets the very blocks it will get later
+            candidates = rings + ([(None, None)] if n == n_ring or not rings else [])
             for vi, (vol, mem) in enumerate(vols):
                 self._sh_packed, self._sh_memory = vol, mem
                 self._destroy_handle()
                 self._n_max = 0
                 row = []
-                for ri, (ring, rmem) in enumerate(rings or [(None, None)]):
+                for ri, (ring, rmem) in enumerate(candidates):
                     self._state_ring, self._state_ring_pos = ring, 0
                     state = self._start(seeds[:n])
                     self.profile_begin(16, classes=('state',))
@@ -364,7 +374,13 @@ class BaseEnv(object):
         finally:
             vi, ri = (best[1], best[2]) if best else (0, 0)
             self._sh_packed, self._sh_memory = vols[vi]
-            self._state_ring, self._state_ring_memory = rings[ri] if rings else (None, None)
+            self._state_ring, self._state_ring_memory = None, None
+            if best and candidates[ri][0] is not None:
+                # the ring: the ring_len buffers that were fastest with this volume
+                order = sorted(range(len(rings)), key=lambda r: self._sh_tuned[vi][r])
+                picked = [rings[r] for r in order[:ring_len]]
+                self._state_ring = [bufs[0] for bufs, _ in picked]
+                self._state_ring_memory = [m for _, m in picked]
             self._state_ring_pos = 0
             self._destroy_handle()
             self._n_max = 0
