@@ -20,9 +20,10 @@ export TMPDIR=/tmp
 O=gpurun_out/prof_$tag
 mkdir -p $O
 T="timeout -k 10 400"
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/bench_under_rocprof.json 2> $O/stats.log
-$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --no-cpu-baseline --no-whole-episode > /dev/null 2> $O/fetch.log
-$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --no-cpu-baseline --no-whole-episode > /dev/null 2> $O/write.log
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/stats.json 2> $O/stats.log
+cp $O/stats.json $O/bench_under_rocprof.json
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/fetch.json 2> $O/fetch.log
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/write.json 2> $O/write.log
 python3 profiles/pmc_summary.py $tag $O/stats $O/fetch $O/write
 $T python3 bench.py > $O/bench.json
 R=gpurun_out/profiles_$tag

@@ -35,14 +35,37 @@ def short(name):
     return m.group(1).replace(' ', '') if m else name
 
 
+def search_launches(dirname):
+    """State-gather launches of the placement search in the run that wrote
+    `dirname` (env.py:_tune_placement: a reset + four steps per pair, before
+    anything else): 5 x the entries of `placement_candidates_ms` in the bench
+    line the run printed (<dirname>.json).  They are excluded from the per-launch
+    averages: many of them rewrite one buffer, which keeps its rows in the caches."""
+    try:
+        line = json.loads(open(dirname.rstrip('/') + '.json').read().strip().splitlines()[-1])
+        return 5 * sum(len(row) for row in line.get('placement_candidates_ms') or [])
+    except (OSError, ValueError, IndexError):
+        return 0
+
+
 def counters(dirname, counter):
     path = glob.glob(os.path.join(dirname, '**', '*_counter_collection.csv'),
                      recursive=True)[0]
-    rows = collections.defaultdict(list)
+    per_dispatch = collections.defaultdict(lambda: [0.0, 0, ''])
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] == counter:
-            rows[short(r['Kernel_Name'])].append(
-                (float(r['Counter_Value']), int(r['Grid_Size'])))
+            d = per_dispatch[int(r['Dispatch_Id'])]
+            d[0] += float(r['Counter_Value'])
+            d[1] = int(r['Grid_Size'])
+            d[2] = short(r['Kernel_Name'])
+    rows = collections.defaultdict(list)
+    for disp in sorted(per_dispatch):
+        v, g, k = per_dispatch[disp]
+        rows[k].append((v, g))
+    skip = search_launches(dirname)
+    for k in rows:
+        if k.startswith('k_state') and skip and len(rows[k]) > skip:
+            rows[k] = rows[k][skip:]
     return rows
 
 
@@ -55,17 +78,22 @@ def durations_by_size(stats_dir):
     if not paths:
         return []
     groups = collections.defaultdict(list)
-    for r in csv.DictReader(open(paths[0])):
+    rows = sorted(csv.DictReader(open(paths[0])), key=lambda r: int(r['Start_Timestamp']))
+    skip, seen = search_launches(stats_dir), 0
+    for r in rows:
         k = short(r['Kernel_Name'])
         if not k.startswith('k_state'):
             continue
+        seen += 1
         grid = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
         m = re.match(r'k_state(?:_dd)?<(\d+)', k)
         units = grid // 256 * (4 * (64 // int(m.group(1))) if m else 20)
         dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3      # us
-        groups[(k, 'more than 200 000 rows (steps and resets of the windows)' if units > 200000
-                else 'at most 200 000 rows (placement search, warm-up tail)')].append((dur, units))
-    out = ['state gather by launch size, rocprofv3 kernel trace of the --stats pass:']
+        what = 'placement search (the first %d launches)' % skip if seen <= skip else \
+            ('steps and resets of the windows (more than 200 000 rows)' if units > 200000
+             else 'at most 200 000 rows')
+        groups[(k, what)].append((dur, units))
+    out = ['state gather by phase, rocprofv3 kernel trace of the --stats pass:']
     for (k, what), rows in sorted(groups.items()):
         out.append(f'{k} | {what} | {len(rows)} launches | '
                    f'{sum(u for _, u in rows) / len(rows):.0f} rows avg | '
