@@ -33,6 +33,14 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: only the entry points marked
+ * TTL_API below are exported (nm -D shows exactly these). */
+#if defined(__GNUC__) || defined(__clang__)
+#define TTL_API __attribute__((visibility("default")))
+#else
+#define TTL_API
+#endif
+
 #define TTL_ABI_VERSION 7
 
 #define TTL_OK 0
@@ -125,7 +133,7 @@ typedef struct ttl_env_desc {
 typedef struct ttl_env ttl_env;
 
 /* Bytes of device scratch the handle needs for n_max streamlines. */
-size_t ttl_env_workspace_bytes(int32_t n_max);
+TTL_API size_t ttl_env_workspace_bytes(int32_t n_max);
 
 /* Order of the packed voxel records:
  *   TTL_SH_LINEAR  [X][Y][Z] as the source volume;
@@ -139,7 +147,7 @@ size_t ttl_env_workspace_bytes(int32_t n_max);
 #define TTL_SH_BRICK4 1
 
 /* Number of voxel records ttl_pack_sh_volume() writes for a volume. */
-int64_t ttl_sh_volume_records(const int32_t *dim /*[3]*/, int32_t layout);
+TTL_API int64_t ttl_sh_volume_records(const int32_t *dim /*[3]*/, int32_t layout);
 
 /* Device memory for a volume the step gathers from (the packed SH volume):
  * try_contiguous 0: plain hipMalloc; 1: physically contiguous
@@ -156,29 +164,29 @@ int64_t ttl_sh_volume_records(const int32_t *dim /*[3]*/, int32_t layout);
  * buffers into a few allocations obtained here, time the step's own gather on
  * every pair at the first large reset and keep the fastest; the caching
  * allocator would hand the same block back every time. */
-int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void **out,
+TTL_API int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void **out,
                      int32_t *contiguous_out);
-int ttl_volume_free(void *ptr);
+TTL_API int ttl_volume_free(void *ptr);
 
 
 /* Repack an SH volume [X][Y][Z][C] f32 (the layout of
  * TTL/environments/env.py:169-180 `data_volume`) into 16-byte aligned voxel
  * records of coef_pitch floats, zero padded, in `layout` order; dst holds
  * ttl_sh_volume_records(dim, layout) records.  Once per subject. */
-int ttl_pack_sh_volume(const float *src, float *dst, const int32_t *dim /*[3]*/,
+TTL_API int ttl_pack_sh_volume(const float *src, float *dst, const int32_t *dim /*[3]*/,
                        int32_t n_coef, int32_t coef_pitch, int32_t layout,
                        void *hip_stream);
 
 /* Per-cell shortcut table for the mask test (see ttl_env_desc.mask_classes):
  * 1 = all 64 spline taps of the cell are >= threshold, 2 = all are below,
  * 0 = undecided.  Once per subject and threshold. */
-int ttl_mask_classes(const double *mask_coef, const int32_t *dim /*[3]*/,
+TTL_API int ttl_mask_classes(const double *mask_coef, const int32_t *dim /*[3]*/,
                      double threshold, uint8_t *classes_out, void *hip_stream);
 
 /* Validates the descriptor and creates a handle (no device work).
  * Replaces the per-subject setup of BaseEnv.load_subject, env.py:143-281. */
-int ttl_env_create(const ttl_env_desc *desc, ttl_env **out);
-void ttl_env_destroy(ttl_env *env);
+TTL_API int ttl_env_create(const ttl_env_desc *desc, ttl_env **out);
+TTL_API void ttl_env_destroy(ttl_env *env);
 
 /* TrackingEnvironment.reset / nreset (tracking_env.py:91-133 / 47-89):
  * n seeds (float32 [n][3], voxel space) become streamlines 0..n-1 of one
@@ -192,7 +200,7 @@ void ttl_env_destroy(ttl_env *env);
  * the library to build that order itself (as ttl_env_refresh_processing_order
  * does later in the episode). */
 #define TTL_ORDER_BY_POSITION ((const int32_t *)(uintptr_t)1)
-int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
+TTL_API int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
                   const int32_t *processing_order, float *state_out,
                   int64_t state_pitch, void *hip_stream);
 
@@ -211,7 +219,9 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
  *             that computes the counts -- k_prefix, before the state gather
  *             has even started, or the one-launch tail of batches of at most
  *             16384 rows -- writes them and then a process-unique sequence
- *             number straight into it, and ttl_env_wait_counts() polls that
+ *             number (bit 30 set, so that it can never equal the "steps done"
+ *             count a free-running episode leaves in the same word) straight
+ *             into it, and ttl_env_wait_counts() polls that
  *             word: the host can queue the next step while this one's gather
  *             is still running, with no copy kernel competing for the CUs.
  *             Otherwise (or with TTL_POLL_COUNTS=0) the counts are copied on
@@ -219,7 +229,7 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
  * Normalise + scale the action, first-step flip, grow by one point, LENGTH /
  * CURVATURE / MASK stopping tests, flags and dones, alignment reward, new
  * state.  continue_idx itself only changes in ttl_env_harvest(). */
-int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
+TTL_API int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
                  int32_t n_active, int32_t order, float *state_out,
                  int64_t state_pitch, double *reward_out, uint8_t *done_out,
                  int32_t *host_counts, void *hip_stream);
@@ -233,10 +243,10 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
  *   ttl_env_step_end    ORs extra_flags (may be NULL) into flags / dones /
  *                       done_out, compacts, writes the state rows.
  * ttl_env_step() == begin + end(NULL). */
-int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
+TTL_API int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
                        int32_t n_active, double *reward_out, uint8_t *done_out,
                        void *hip_stream);
-int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
+TTL_API int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
                      float *state_out, int64_t state_pitch, int32_t *host_counts,
                      void *hip_stream);
 
@@ -244,7 +254,7 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
  * ttl_env_step() have landed (not until the step has finished).  Called after
  * ttl_env_harvest() it also tells the handle the exact survivor count, and
  * the next ttl_env_step() is then refused unless n_active equals it. */
-int ttl_env_wait_counts(ttl_env *env);
+TTL_API int ttl_env_wait_counts(ttl_env *env);
 
 /* TrackingEnvironment.harvest (tracking_env.py:223-245): lengths of the
  * streamlines that stopped in the last step, continue_idx <- survivors
@@ -252,14 +262,14 @@ int ttl_env_wait_counts(ttl_env *env);
  * survivors' rows are copied from state_in (the step's output) to the first
  * n_continue rows of state_out.  After an ORDER_PARTITION step nothing is
  * launched (the lengths were written by the step itself). */
-int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
+TTL_API int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
                     int64_t state_pitch, void *hip_stream);
 
 /* ttl_env_harvest() followed by ttl_env_wait_counts() in one call (one trip
  * through the FFI instead of two; small batches are host bound): returns the
  * survivor count through n_continue_out.  The last step must have been given
  * host_counts. */
-int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
+TTL_API int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
                          int64_t state_pitch, void *hip_stream,
                          int32_t *n_continue_out);
 
@@ -296,16 +306,16 @@ int ttl_env_harvest_wait(ttl_env *env, const float *state_in, float *state_out,
  *   +0.0).
  * end: waits for the stream, reads the device words back into the handle
  *   (which then continues as after a harvest) and returns them. */
-int ttl_env_freerun_begin(ttl_env *env, int32_t *host_counts, void *hip_stream);
-int ttl_env_freerun_step(ttl_env *env, const float *actions, int32_t n_rows,
+TTL_API int ttl_env_freerun_begin(ttl_env *env, int32_t *host_counts, void *hip_stream);
+TTL_API int ttl_env_freerun_step(ttl_env *env, const float *actions, int32_t n_rows,
                          float *state_out, int64_t state_pitch, double *reward_out,
                          uint8_t *done_out, void *hip_stream);
-int ttl_env_freerun_end(ttl_env *env, int32_t *n_active_out, int32_t *length_out,
+TTL_API int ttl_env_freerun_end(ttl_env *env, int32_t *n_active_out, int32_t *length_out,
                         int32_t *steps_out, void *hip_stream);
 /* Measurement only: ttl_scripted_actions() for a free-running step -- the row
  * count, the step number (length - 1) and the live continue_idx buffer are
  * read from the device words; rows 0..min(n_active, n_rows)-1 are written. */
-int ttl_env_freerun_scripted_actions(ttl_env *env, const float *state, int64_t state_pitch,
+TTL_API int ttl_env_freerun_scripted_actions(ttl_env *env, const float *state, int64_t state_pitch,
                                      int32_t dir_offset, int32_t n_rows, uint32_t seed,
                                      float wobble, float *actions_out, void *hip_stream);
 
@@ -314,7 +324,7 @@ int ttl_env_freerun_scripted_actions(ttl_env *env, const float *state, int64_t s
  * streamlines that have n_points points each (with n_points == 2 the first
  * entry of a tail is ignored, with n_points == 1 the first two are).
  * flags_out[n] u8 = OR of TTL_FLAG_* (0 = keeps going).  Touches no env state. */
-int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
+TTL_API int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
                            int32_t n_points, uint8_t *flags_out,
                            void *hip_stream);
 
@@ -325,18 +335,18 @@ int ttl_env_stopping_flags(ttl_env *env, const float *tail, int32_t n,
  * ROW order, not this): results do not depend on it.  The host classes
  * refresh it every few steps from the streamlines' current positions, because
  * an order sorted by seed position decays as the streamlines travel. */
-int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
+TTL_API int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
                                  void *hip_stream);
 
 /* The same, computed by the library: active rows sorted by the 8^3-voxel brick
  * of their streamline's newest point (key kernel + counting sort on workspace
  * memory, no allocation).  Between a harvest and the next step, after the
  * survivor count has been read back. */
-int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream);
+TTL_API int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream);
 
 /* Current continue_idx buffer (device, int32 [n_active]) and, after a step,
  * the active-row -> output-row map (device, int32 [n_active]). */
-int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
+TTL_API int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
                  const int32_t **row_dest, int32_t *length);
 
 /* Measurement support (bench.py): while profiling is on, every kernel launched
@@ -344,9 +354,9 @@ int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
  * ttl_env_profile_end() synchronises those events and returns, per kernel
  * class {0: advance, 1: prefix, 2: state gather}, the summed duration in ms
  * and the number of launches, then switches profiling off. */
-int ttl_env_profile_begin(ttl_env *env, int32_t max_launches,
+TTL_API int ttl_env_profile_begin(ttl_env *env, int32_t max_launches,
                           int32_t class_mask /* bit k = time class k */);
-int ttl_env_profile_end(ttl_env *env, double *total_ms /*[3]*/,
+TTL_API int ttl_env_profile_end(ttl_env *env, double *total_ms /*[3]*/,
                         int32_t *n_launches /*[3]*/);
 
 /* Scripted, policy-free actions for "env.step only" runs (stands in
@@ -355,7 +365,7 @@ int ttl_env_profile_end(ttl_env *env, double *total_ms /*[3]*/,
  * segment being state[i][dir_offset .. dir_offset+2] (dir_offset = 7*C).  The
  * noise is a counter-based hash of (seed, step, continue_idx[i], component),
  * reproduced bit for bit by oracle/scripted_policy.py. */
-int ttl_scripted_actions(const float *state, int64_t state_pitch,
+TTL_API int ttl_scripted_actions(const float *state, int64_t state_pitch,
                          int32_t dir_offset, const int32_t *continue_idx,
                          int32_t n, uint32_t seed, uint32_t step, float wobble,
                          float *actions_out, void *hip_stream);
@@ -373,7 +383,7 @@ int ttl_scripted_actions(const float *state, int64_t state_pitch,
  * |cos| to every kept peak <= min_separation_cos.  peaks_out:
  * [n_voxels][3*npeaks] f32, zeros for voxels whose coefficients sum to 0 and
  * for missing peaks.  All pointers are device memory. */
-int ttl_peaks_from_sh(const float *sh, int64_t n_voxels, int32_t n_coef,
+TTL_API int ttl_peaks_from_sh(const float *sh, int64_t n_voxels, int32_t n_coef,
                       const float *sf_matrix, const float *vertices,
                       const int32_t *neighbours, int32_t n_vertices, int32_t degree,
                       int32_t npeaks, float relative_threshold, float absolute_threshold,
@@ -387,15 +397,15 @@ int ttl_peaks_from_sh(const float *sh, int64_t n_voxels, int32_t n_coef,
  * points per row; out: [n][nb_points][3] f32.  First and last point are kept,
  * the others sit at arc length k * total / (nb_points - 1) (float64), linearly
  * interpolated inside their segment.  Device pointers. */
-int ttl_resample_streamlines(const float *points, int64_t row_pitch,
+TTL_API int ttl_resample_streamlines(const float *points, int64_t row_pitch,
                              const int32_t *lengths32, const int64_t *lengths64,
                              int32_t n, int32_t max_len, int32_t nb_points, float *out,
                              void *hip_stream);
 
-const char *ttl_last_error(void);
-uint32_t ttl_abi_version(void);
+TTL_API const char *ttl_last_error(void);
+TTL_API uint32_t ttl_abi_version(void);
 /* sizeof(ttl_env_desc) as compiled: a binding checks its own struct against it */
-size_t ttl_env_desc_size(void);
+TTL_API size_t ttl_env_desc_size(void);
 
 #ifdef __cplusplus
 }

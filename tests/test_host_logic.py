@@ -24,6 +24,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.ttl_abi_version() == _lib.ABI_VERSION
     assert lib.ttl_env_workspace_bytes(1024) > 1024 * 13
+    # built with -fvisibility=hidden: nothing but the TTL_API entry points (and
+    # the toolchain's own __hip_* / std:: data symbols) leaves the library
+    import shutil
+    import subprocess
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    if os.path.exists(nm) or shutil.which(nm):
+        out = subprocess.run([nm, '-D', '--defined-only', _lib.LIB_PATH],
+                             capture_output=True, text=True, check=True).stdout
+        rows = [r.split() for r in out.splitlines() if r.strip()]
+        functions = {r[-1] for r in rows if r[-2] in ('T', 'W', 't', 'w')}
+        assert functions == declared, functions ^ declared
+        assert not [r[-1] for r in rows if 'ttl_detail' in r[-1]]
 
 
 def test_descriptor_layout_matches_header():

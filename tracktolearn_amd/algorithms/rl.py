@@ -59,7 +59,7 @@ class RLAlgorithm(object):
             agent = self.agent
             out = env.run_free(
                 lambda s: agent.select_action(s, probabilistic=prob), initial_state,
-                key=(id(agent), float(prob)),
+                key=(id(agent), float(prob)), owner=agent,
                 max_policy_us=getattr(self, 'graph_policy_us', RLAlgorithm.graph_policy_us))
             if out is None and not prob and os.environ.get('TTL_FREE_RUNNING_EAGER', '0') == '1':
                 # Opt-in: the policy is too expensive to run on the full batch at

@@ -25,6 +25,8 @@ FLAGS = [
     # IEEE divide and sqrt, no fast-math
     '-ffp-contract=off', '-fno-fast-math',
     '-fhip-fp32-correctly-rounded-divide-sqrt',
+    # only the TTL_API entry points of include/ttl_hip.h leave the library
+    '-fvisibility=hidden', '-fvisibility-inlines-hidden',
     '-Wall', '-Wno-unused-function',
 ]
 
@@ -48,11 +50,19 @@ def up_to_date():
 def build(force=False, verbose=True):
     if not force and up_to_date():
         return OUTPUT
+    # link into a temporary name and rename: a process that has the old
+    # library mapped keeps its (unlinked) file instead of seeing it truncated
+    tmp = OUTPUT + f'.tmp{os.getpid()}'
     cmd = [find_hipcc()] + FLAGS + ['-I', os.path.join(ROOT, 'include'), '-I', HERE] + \
-        SOURCES + ['-o', OUTPUT]
+        SOURCES + ['-o', tmp]
     if verbose:
         print(' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, OUTPUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return OUTPUT
 
 

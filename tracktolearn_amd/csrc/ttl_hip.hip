@@ -1027,7 +1027,13 @@ int ttl_volume_alloc(int32_t device, size_t bytes, int32_t try_contiguous, void 
     hipError_t e = hipSuccess;
     if (!p) e = hipMalloc(&p, bytes);
     if (device >= 0 && device != prev) (void)hipSetDevice(prev);
-    if (e != hipSuccess) return fail(TTL_ERR_HIP, "ttl_volume_alloc: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        // callers probe for room with this call (BaseEnv._tune_placement): the
+        // runtime keeps the last error until it is read, and the next launch
+        // check -- ours or torch's -- would report this one as its own
+        (void)hipGetLastError();
+        return fail(TTL_ERR_HIP, "ttl_volume_alloc: %s", hipGetErrorString(e));
+    }
     *out = p;
     if (contiguous_out) *contiguous_out = contiguous;
     return TTL_OK;
@@ -1453,9 +1459,11 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
                 (void)hipGetLastError();      // not pinned: copy path below
         }
         host_word = env->host_dev;
-        static std::atomic<int> g_seq{1};
-        seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
-        if (seq == 0) seq = g_seq.fetch_add(1, std::memory_order_relaxed) & 0x7fffffff;
+        // sequence numbers carry bit 30: word [2] of the same pinned buffer is
+        // the "steps done" counter of a free-running episode (small values), and
+        // a leftover count must never read as this step's sequence number
+        static std::atomic<unsigned> g_seq{1};
+        seq = (int)((g_seq.fetch_add(1, std::memory_order_relaxed) & 0x3fffffffu) | 0x40000000u);
     }
     if (host_word) {
         env->counts_pending = 2;

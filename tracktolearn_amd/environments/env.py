@@ -261,8 +261,14 @@ class BaseEnv(object):
     #: allocation of the volume and fresh state tensors per step)
     VOLUME_CANDIDATES = 3
     STATE_RING_CANDIDATES = 16
-    #: device memory the ring candidates may hold together during the search
-    STATE_RING_SEARCH_BYTES = 32 << 30
+    #: device memory the search may hold on top of the env's own (the extra
+    #: copies of the volume + the candidate state buffers): at most this much and
+    #: at most PLACEMENT_SEARCH_FREE_FRACTION of what hipMemGetInfo reports free
+    PLACEMENT_SEARCH_BYTES = 8 << 30
+    PLACEMENT_SEARCH_FREE_FRACTION = 0.10
+    #: the search stops after its first three pairs when their gather times agree
+    #: within this fraction (a box without placement classes: nothing to find)
+    PLACEMENT_EARLY_EXIT = 0.02
     #: volumes below this sit in the caches wherever they are
     VOLUME_TUNE_MIN_BYTES = 64 << 20
     #: batches below this are bound by launches, not by the gather
@@ -279,6 +285,7 @@ class BaseEnv(object):
             self.data_volume.data_ptr(), vol.data_ptr(), dims, n_coef, pitch,
             self._sh_layout, self._stream()), 'ttl_pack_sh_volume')
         self._sh_tuned = None          # the matrix of candidate times once tuned
+        self._placement_search = None  # what the search did (see _tune_placement)
         self._state_ring, self._state_ring_pos, self._state_ring_memory = None, 0, None
         return vol, mem
 
@@ -303,7 +310,18 @@ class BaseEnv(object):
         addresses: no result changes): its volume is kept, and the STATE_RING
         buffers that were fastest with that volume form the ring.  The caching
         allocator's own blocks (no ring: a fresh state tensor per step) are the
-        17th candidate for the rows when the probe runs at the batch's own size."""
+        17th candidate for the rows when the probe runs at the batch's own size.
+
+        Bounded (round 3): the extra volume copies and the candidate buffers
+        together take at most PLACEMENT_SEARCH_BYTES and at most
+        PLACEMENT_SEARCH_FREE_FRACTION of the device memory that is free when
+        the search starts (fewer candidates otherwise, none when even
+        STATE_RING buffers do not fit); when the first three pairs agree within
+        PLACEMENT_EARLY_EXIT the box has no placement classes worth a search
+        and it stops there.  ``_placement_search`` records what was done
+        (seconds, bytes held, pairs timed, early exit)."""
+        import time
+        t_search = time.perf_counter()
         kv = int(os.environ.get('TTL_VOLUME_CANDIDATES', self.VOLUME_CANDIDATES))
         kr = int(os.environ.get('TTL_STATE_RING_CANDIDATES', self.STATE_RING_CANDIDATES))
         ring_len = int(os.environ.get('TTL_STATE_RING', self.STATE_RING))
@@ -319,8 +337,25 @@ class BaseEnv(object):
         n_ring = len(seeds)                     # the batch that triggered the tuning
         n = min(n_ring, 262144)
         buf_bytes = n_ring * self._state_pitch * 4
+        # memory budget of the search, from what the device reports free now
+        try:
+            free_bytes = int(torch.cuda.mem_get_info(self._device_index)[0])
+        except Exception:           # pragma: no cover
+            free_bytes = 0
+        budget = int(min(self.PLACEMENT_SEARCH_BYTES,
+                         self.PLACEMENT_SEARCH_FREE_FRACTION * free_bytes))
+        budget = int(os.environ.get('TTL_PLACEMENT_SEARCH_BYTES', budget))
+        kv = max(1, min(kv, 1 + budget // max(2 * nbytes, 1)))   # copies: half of it at most
+        left = budget - (kv - 1) * nbytes
         if kr > 0:
-            kr = max(ring_len, min(kr, self.STATE_RING_SEARCH_BYTES // max(buf_bytes, 1)))
+            kr = min(kr, left // max(buf_bytes, 1))
+            if kr < ring_len:
+                kr = 0
+        self._placement_search = dict(budget_bytes=budget, free_bytes_at_start=free_bytes,
+                                      volume_candidates=kv, state_buffer_candidates=kr,
+                                      pairs_timed=0, early_exit=False, seconds=0.0)
+        if kv < 2 and kr == 0:
+            return
         keep = dict(initial_points=getattr(self, 'initial_points', None),
                     noise=getattr(self, 'noise', None))
         if keep['noise'] is not None:
@@ -351,7 +386,12 @@ class BaseEnv(object):
             # without a ring) compete too when the probe runs at the batch's own
             # size: a step then gets the very blocks it will get later
             candidates = rings + ([(None, None)] if n == n_ring or not rings else [])
+            self._placement_search['bytes_held'] = (len(vols) - 1) * nbytes + \
+                len(rings) * buf_bytes
+            timed, settled = [], False
             for vi, (vol, mem) in enumerate(vols):
+                if settled:
+                    break
                 self._sh_packed, self._sh_memory = vol, mem
                 self._destroy_handle()
                 self._n_max = 0
@@ -370,14 +410,25 @@ class BaseEnv(object):
                     row.append(round(ms, 5))
                     if best is None or ms < best[0]:
                         best = (ms, vi, ri)
+                    timed.append(ms)
+                    if len(timed) == 3 and min(timed) > 0 and \
+                            max(timed) - min(timed) <= self.PLACEMENT_EARLY_EXIT * min(timed) \
+                            and os.environ.get('TTL_PLACEMENT_EARLY_EXIT', '1') != '0':
+                        settled = True      # no classes on this box: nothing to find
+                        break
                 self._sh_tuned.append(row)
+            self._placement_search.update(pairs_timed=len(timed), early_exit=settled)
         finally:
             vi, ri = (best[1], best[2]) if best else (0, 0)
             self._sh_packed, self._sh_memory = vols[vi]
             self._state_ring, self._state_ring_memory = None, None
             if best and candidates[ri][0] is not None:
                 # the ring: the ring_len buffers that were fastest with this volume
-                order = sorted(range(len(rings)), key=lambda r: self._sh_tuned[vi][r])
+                # (buffers the search never timed -- early exit -- rank last, in
+                # allocation order)
+                row = self._sh_tuned[vi]
+                order = sorted(range(len(rings)),
+                               key=lambda r: (row[r] if r < len(row) else float('inf'), r))
                 picked = [rings[r] for r in order[:ring_len]]
                 self._state_ring = [bufs[0] for bufs, _ in picked]
                 self._state_ring_memory = [m for _, m in picked]
@@ -387,6 +438,9 @@ class BaseEnv(object):
             self.initial_points = keep['initial_points']
             if keep['noise'] is not None:
                 self.noise = keep['noise']
+            del vols, rings, candidates          # the losers go back to the driver
+            if getattr(self, '_placement_search', None) is not None:
+                self._placement_search['seconds'] = time.perf_counter() - t_search
 
     def _derive_tracking_params(self):
         """env.py:196-213: step size in voxels, step counts and the

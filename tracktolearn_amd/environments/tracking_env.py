@@ -59,8 +59,14 @@ class _FreeRun:
     """The captured graph of one free-running step (policy + env launches) and
     the fixed buffers it works on."""
 
-    def __init__(self, env, n, policy, record_actions):
+    def __init__(self, env, n, policy, record_actions, owner=None):
         dev = env.device
+        # the captured graph holds raw pointers to the policy's weights: keep
+        # the owner alive and remember which storages were captured, so that a
+        # replaced network (or another agent recycled at the same id()) is
+        # noticed instead of replayed on freed memory
+        self.owner = owner
+        self.fingerprint = _policy_fingerprint(owner)
         self.state = env._new_state(n)
         self.state.zero_()
         self.done = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -95,8 +101,8 @@ class _FreeRun:
     def capture(self, env, policy):
         """Between ttl_env_freerun_begin and _end: record policy + step."""
         n, record_actions = self.state.shape[0], self.actions_log is not None
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
             with torch.no_grad():
                 a = policy(self.state)
             a = a.to(torch.float32).contiguous()
@@ -112,6 +118,19 @@ class _FreeRun:
             if self.reward is not None:
                 self.reward_sum += self.reward.sum()
             self.actions = a
+        self.graph = graph          # only a capture that went through is replayed
+
+
+def _policy_fingerprint(owner):
+    """Storage addresses of the parameters a captured policy reads (the owner's
+    own and its ``actor``'s when those are torch modules)."""
+    if owner is None:
+        return None
+    mods = []
+    for m in (owner, getattr(owner, 'actor', None), getattr(owner, 'agent', None)):
+        if isinstance(m, torch.nn.Module) and all(m is not k for k in mods):
+            mods.append(m)
+    return tuple(p.data_ptr() for m in mods for p in m.parameters())
 
 
 class TrackingEnvironment(BaseEnv):
@@ -487,7 +506,8 @@ class TrackingEnvironment(BaseEnv):
         self.not_stopping = None
         return reward_sum, n_steps
 
-    def run_free(self, policy, state, key=None, record_actions=False, max_policy_us=None):
+    def run_free(self, policy, state, key=None, record_actions=False, max_policy_us=None,
+                 owner=None):
         """Track the current batch to exhaustion without the host in the loop
         (what ``RLAlgorithm.validation_episode`` does with ``step_device`` /
         ``harvest``, rl.py:58-106): ``policy(state) -> actions`` and the step's
@@ -499,7 +519,10 @@ class TrackingEnvironment(BaseEnv):
 
         ``policy`` must be torch code that can run under stream capture (no
         host round trip) and treat rows independently.  ``key`` identifies it
-        for the graph cache (default ``id(policy)``).  Returns ``(summed reward
+        for the graph cache (default ``id(policy)``); ``owner`` (the agent whose
+        networks the policy evaluates) is kept alive with the cached graph, and
+        the graph is captured again when another owner turns up under the same
+        key or its parameters have moved to other storage.  Returns ``(summed reward
         as a 0-d float64 tensor or None, number of steps)``; with
         ``record_actions`` also the ``(steps, n, 3)`` action batches.
 
@@ -515,6 +538,10 @@ class TrackingEnvironment(BaseEnv):
         n = self._n_active
         key = (n, id(policy) if key is None else key, bool(record_actions))
         fr = self._free_runs.get(key)
+        if fr is not None and (fr.owner is not owner or
+                               fr.fingerprint != _policy_fingerprint(owner)):
+            del self._free_runs[key]        # captured over other weights
+            fr = None
         if fr is not None and max_policy_us is not None and fr.policy_us > max_policy_us:
             return None         # a replayed graph would lose to the shrinking batches
         _lib.check(self._lib.ttl_env_freerun_begin(
@@ -525,11 +552,15 @@ class TrackingEnvironment(BaseEnv):
                 # may itself read the free-running words: timed after begin)
                 if len(self._free_runs) >= 8:       # keys normally repeat (batch size, agent)
                     self._free_runs.clear()
-                fr = self._free_runs[key] = _FreeRun(self, n, policy, record_actions)
+                fr = self._free_runs[key] = _FreeRun(self, n, policy, record_actions, owner)
                 if max_policy_us is not None and fr.policy_us > max_policy_us:
                     return None
             if fr.graph is None:
-                fr.capture(self, policy)
+                try:
+                    fr.capture(self, policy)
+                except BaseException:
+                    self._free_runs.pop(key, None)
+                    raise
             fr.state[:n].copy_(state)
             if fr.reward_sum is not None:
                 fr.reward_sum.zero_()
