@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- streamline-steps/s of the MI355X environment step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows M]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows M] [--legs ...]
 
-Workload (BASELINE.json configs[1]): "env.step only" on a
-synthetic 96^3 x 45-SH volume, n_actor = 262144 streamlines per GPU, ball
+Headline workload (BASELINE.json configs[1]): "env.step only" on
+a synthetic 96^3 x 45-SH volume, n_actor = 262144 streamlines per GPU, ball
 mask, step 0.75 mm, theta 30 deg, max_length 200 mm, n_dirs = 4, reward off,
 float32 (training-env) arithmetic, scripted policy-free actions generated on
 the GPU (counter-based; `ttl_scripted_actions`).
@@ -20,17 +20,35 @@ started from a fresh (untimed) reset, so all windows time the same K steps.
 window); min / max over the windows are printed next to them (`windows`).
 Every second window also brackets the dominant kernel with HIP events (for
 `roofline`); those records cost a few percent, both medians are printed.
-One 12-step window is ~3 ms of GPU time, which is why one window alone is a
-fragile figure.
 
 With N > 1 the driver launches one process per GPU (torch.distributed.run);
 called bare with --gpus N > 1 this script launches those N ranks itself (as
 child processes, before this process touches the GPU) and relays rank 0's
 line.  Streamlines shard across ranks with the volumes replicated and no
-collective on the step path ("scaling": "weak": n_actor per GPU is fixed).
-The one exchange the path has -- collating finished tracts on rank 0 (exact-
-size gather to root over RCCL) -- runs after the timed region and is reported
+collective on the step path.  The one exchange the path has -- collating
+finished tracts on rank 0 (exact-size gather to root over RCCL) -- is timed
 as `collate_ms`.
+
+Legs (all of them by default; `--legs weak,hbm` etc. restricts, which is how
+the rocprofv3 passes under profiles/ look at one workload at a time):
+
+  weak     the headline: 262144 streamlines PER GPU ("scaling": "weak").
+           -> `value`, `windows`, `roofline`, `whole_episode`, `collate_ms`.
+  strong   BASELINE's metric as stated, "at n_actor = 262144": 262144
+           streamlines in TOTAL, rank r tracks the contiguous shard
+           shard_bounds(262144, r, N) of one global seed batch.  -> `strong`.
+           (At N = 1 weak and strong are the same run.)
+  config4  BASELINE configs[3]: 145^3 x 45 volume (585 MB packed: does not fit
+           the 256 MB Infinity Cache), 1048576 streamlines in total sharded
+           over the N ranks (131072 per GPU at N = 8), n_dirs = 100, float64
+           directions (NoisyTrackingEnvironment, sigma 0), max_length 300 mm.
+           Step-only windows as above, and one whole tractogram end to end:
+           every streamline tracked to exhaustion, then the finished tracts
+           collated on rank 0 -- `collate_ms` INCLUDED in the end-to-end
+           streamline-steps/s printed next to the step-only one.  -> `config4`.
+  hbm      the `roofline` object again in the regime where HBM binds: one
+           GPU's shard of config 4 at N = 8 (131072 streamlines on the 145^3
+           volume).  -> `roofline_hbm_regime` (rank 0's kernel times).
 
 Extra objects on the JSON line:
   roofline     dominant kernel (k_state_dd: 7-point SH gather + state row
@@ -47,7 +65,7 @@ Extra objects on the JSON line:
   cpu_baseline the CPU oracle (oracle/env_oracle.py, a port of the reference's
                NumPy env) timed on this box's host cores on a bounded sample:
                1 thread, and all the cores this process may use (the
-               streamlines sharded over worker processes).
+               streamlines sharded over worker processes).  N = 1 only.
 """
 import argparse
 import json
@@ -63,16 +81,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-D = 96
 C = 45
-N_ACTOR = 262144
-N_DIRS = 4
 STEP_MM = 0.75
 THETA = 30.0
-MAX_LENGTH = 200.0
 WOBBLE = 0.05
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DOMINANT_KERNEL = 'k_state_dd<12,4,false,true>'
+
+#: the two volumes the legs run on (BASELINE.json configs[1] and configs[3])
+WORKLOADS = {
+    'c2': dict(D=96, n_total=262144, n_dirs=4, noisy=False, max_length=200.0,
+               what='96^3x45-SH synthetic volume, n_dirs=4, float32 directions '
+                    '(train env), max_length 200 mm'),
+    'c4': dict(D=145, n_total=1048576, n_dirs=100, noisy=True, max_length=300.0,
+               what='145^3x45-SH synthetic volume (ISMRM2015-shaped), n_dirs=100, float64 '
+                    'directions (NoisyTrackingEnvironment, sigma 0), max_length 300 mm'),
+}
+D = WORKLOADS['c2']['D']
+N_ACTOR = WORKLOADS['c2']['n_total']
+N_DIRS = WORKLOADS['c2']['n_dirs']
+MAX_LENGTH = WORKLOADS['c2']['max_length']
+#: rows of the HBM-regime roofline leg: one GPU's shard of config 4 at N = 8
+HBM_LEG_ROWS = 131072
+LEGS = ('weak', 'strong', 'config4', 'hbm')
 
 
 def algorithmic_bytes(c, k):
@@ -97,32 +128,45 @@ def compulsory_bytes(c, k, n_mask_voxels, units_per_launch):
     return row + per_streamline + n_mask_voxels * record / max(units_per_launch, 1.0)
 
 
-def make_subject():
+def make_subject(workload='c2'):
     from tracktolearn_amd.utils.synthetic import synthetic_subject
-    return synthetic_subject(D, C, seed=1234, peaks=False, affine_dtype=np.float32)
+    w = WORKLOADS[workload]
+    return synthetic_subject(w['D'], C, seed=1234, peaks=False,
+                             affine_dtype=np.float64 if w['noisy'] else np.float32)
 
 
-def make_env(subject, device, seed_offset):
+def make_env(subject, device, workload='c2'):
+    """The environment of a workload; the caller sets `env.seeds`."""
     import torch
-    from tracktolearn_amd.environments import TrackingEnvironment
-    from tracktolearn_amd.utils.synthetic import synthetic_seeds
-    dto = dict(n_dirs=N_DIRS, theta=THETA, npv=1, binary_stopping_threshold=0.1,
-               step_size=STEP_MM, min_length=20.0, max_length=MAX_LENGTH,
+    from tracktolearn_amd.environments import (NoisyTrackingEnvironment,
+                                               TrackingEnvironment)
+    w = WORKLOADS[workload]
+    dto = dict(n_dirs=w['n_dirs'], theta=THETA, npv=1, binary_stopping_threshold=0.1,
+               step_size=STEP_MM, min_length=20.0, max_length=w['max_length'],
                compute_reward=False, alignment_weighting=1.0, oracle_bonus=0.0,
                rng=np.random.RandomState(0), device=torch.device(device),
-               target_sh_order=8)
-    env = TrackingEnvironment(subject, 'testing', dto)
-    env.seeds = synthetic_seeds(subject[1].data, N_ACTOR, seed=100 + seed_offset)
-    return env
+               target_sh_order=8, noise=0.0, fa_map=None)
+    cls = NoisyTrackingEnvironment if w['noisy'] else TrackingEnvironment
+    return cls(subject, 'testing', dto)
 
 
-def run_steps(env, n_steps, seed, counter):
+def shard_seeds(mask_data, n_total, rank, world, seed=100):
+    """Rank's contiguous shard of ONE global batch of n_total seeds
+    (tracktolearn_amd.parallel.shard_bounds)."""
+    from tracktolearn_amd.parallel import shard_bounds
+    from tracktolearn_amd.utils.synthetic import synthetic_seeds
+    seeds = synthetic_seeds(mask_data, n_total, seed=seed)
+    lo, hi = shard_bounds(n_total, rank, world)
+    return seeds[lo:hi]
+
+
+def run_steps(env, n_steps, seed, counter, rows):
     """n_steps passes of the hot path; returns streamline-steps processed."""
     state = counter['state']
     total = 0
     for _ in range(n_steps):
         if env._n_active == 0:
-            state = env.reset(0, N_ACTOR)
+            state = env.reset(0, rows)
             counter['step'] = 0
             counter['resets'] += 1
         n = env._n_active
@@ -271,6 +315,237 @@ def self_launch(args, argv):
     return 0
 
 
+# --------------------------------------------------------------------------
+# one leg's measurements
+# --------------------------------------------------------------------------
+class Dist:
+    """The process group as the bench uses it: barrier, max / sum over ranks."""
+
+    def __init__(self, world, red_dev):
+        self.world, self.red_dev = world, red_dev
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def reduce(self, values, op):
+        import torch
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64,
+                         device=self.red_dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+
+def timed_windows(env, rows, steps, warmup, n_win, seed, grp):
+    """`warmup` untimed steps, then `n_win` windows of exactly `steps` steps,
+    each from a fresh untimed reset and bracketed by barrier + synchronize.
+    Returns a dict: per-window wall times (max over ranks), streamline-steps of
+    one window (sum over ranks), the dominant kernel's event time on THIS rank."""
+    import torch
+    counter = {'state': env.reset(0, rows), 'step': 0, 'resets': 0}
+    run_steps(env, warmup, seed, counter, rows)
+    # exercise the periodic re-sort of the processing order once outside the
+    # timed regions
+    if env._n_active:
+        env._refresh_processing_order(force=True)
+    torch.cuda.synchronize()
+    # The dominant kernel is bracketed with HIP events in every second window
+    # only: an event record costs ~6 us of GPU idle time on either side of the
+    # kernel (rocprofv3 trace, benchmarks/trace_gaps.py), ~5 % of a step.  All
+    # windows are timed alike and the value is the median over all of them.
+    times, n_units, resets = [], 0, 0
+    state_ms, state_n, evented = 0.0, 0, []
+    for w in range(n_win):
+        counter = {'state': env.reset(0, rows), 'step': 0, 'resets': 0}
+        with_events = (w % 2 == 1) or n_win == 1
+        if with_events:
+            env.profile_begin(max_launches=steps + 8, classes=('state',))
+        grp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_units = run_steps(env, steps, seed, counter, rows)
+        torch.cuda.synchronize()
+        grp.barrier()
+        times.append(time.perf_counter() - t0)
+        resets = max(resets, counter['resets'])
+        if with_events:
+            ms, cnt = env.profile_end()['state']
+            state_ms += ms
+            state_n += cnt
+            evented.append(w)
+    t_all = grp.reduce(times, 'max')            # per window, max over the ranks
+    total_units = float(grp.reduce([n_units], 'sum')[0])     # of ONE window, all ranks
+    t_sorted = np.sort(t_all)
+    t_med = float(t_sorted[len(t_sorted) // 2])
+    rest = [i for i in range(len(t_all)) if i not in evented]
+    return {
+        'value': total_units / t_med, 'ms_per_step': t_med / steps * 1e3,
+        'streamline_steps': total_units, 'rank0_units': n_units, 'resets': resets,
+        'state_ms': state_ms, 'state_n': state_n,
+        'windows': {
+            'n': len(t_all), 'timed': 'each window = exactly --steps steps '
+            'from a fresh untimed reset; value/ms_per_step = median window',
+            'with_kernel_events': evented,
+            'value_median_with_events': (total_units / float(np.median(
+                [t_all[i] for i in evented]))) if evented else None,
+            'value_median_without_events': (total_units / float(np.median(
+                [t_all[i] for i in rest]))) if rest else None,
+            'value_min': total_units / float(t_sorted[-1]),
+            'value_median': total_units / t_med,
+            'value_max': total_units / float(t_sorted[0]),
+            'ms_per_step_min': float(t_sorted[0]) / steps * 1e3,
+            'ms_per_step_max': float(t_sorted[-1]) / steps * 1e3,
+        },
+    }
+
+
+def kernel_breakdown(env, rows, steps, seed):
+    """Untimed replay of a window with every kernel class bracketed (the timed
+    windows only bracket the dominant kernel, to keep the event records out of
+    the other launch gaps): average ms per step of the other kernels."""
+    import torch
+    counter = {'state': env.reset(0, rows), 'step': 0, 'resets': 0}
+    classes = tuple(env.PROFILE_CLASSES)
+    env.profile_begin(max_launches=max(16, steps + 8), classes=classes)
+    run_steps(env, steps, seed, counter, rows)
+    torch.cuda.synchronize()
+    prof = env.profile_end()
+    n_steps = max(prof[classes[0]][1], 1)
+    return {k: prof[k][0] / n_steps for k in classes if k != 'state'}
+
+
+def track_to_exhaustion(env, state, seed, free_tail):
+    """Steps a freshly reset env until no streamline is active; returns (steps,
+    how many of them were free-running)."""
+    ep_steps, free_steps = 0, 0
+    while env._n_active:
+        if free_tail and env.freerun_supported():
+            # from 16 384 rows down a step is bound by the host waiting
+            # for its survivor count: free-running steps, launched for
+            # the newest count the GPU has reported, never waited for
+            _, free_steps = env.run_free_eager(
+                lambda st: env.scripted_actions_free(st, seed, WOBBLE), state)
+            ep_steps += free_steps
+            break
+        actions = env.scripted_actions(state, ep_steps, seed, WOBBLE)
+        env.step_device(actions)
+        state, _ = env.harvest()
+        ep_steps += 1
+    return ep_steps, free_steps
+
+
+def whole_episode(env, rows, seed, free_tail, grp=None):
+    """One episode to exhaustion, the second of two (the first
+    one of a process runs slower: allocator growth and first-use effects a
+    tracking run pays once, on its first seed batch).  With `grp` the episode is
+    bracketed by barriers and the time is the max over ranks."""
+    import torch
+    ep = None
+    for attempt in range(2):
+        state = env.reset(0, rows)
+        torch.cuda.synchronize()
+        if grp is not None:
+            grp.barrier()
+        t_ep = time.perf_counter()
+        ep_steps, free_steps = track_to_exhaustion(env, state, seed, free_tail)
+        torch.cuda.synchronize()
+        t_ep = time.perf_counter() - t_ep
+        # streamline-steps = points added = sum(lengths - 1)
+        ep_units = int(env._buf_lengths[:rows].sum().item()) - rows
+        first = ep
+        ep = {'streamline_steps_per_s_rank0': ep_units / t_ep, 'steps': ep_steps,
+              'streamline_steps': ep_units, 'ms': t_ep * 1e3,
+              'free_running_tail_steps': free_steps,
+              'order_refresh_every': env.SPATIAL_ORDER_REFRESH}
+        if first is not None:
+            ep['first_episode_ms'] = first['ms']
+    return ep
+
+
+def collate(env, grp):
+    """The path's one exchange: every rank's finished tracts gathered on rank 0
+    (exact sizes, RCCL point-to-point).  With one rank there is nothing to
+    exchange: the device-side ragged pack (`tract_arrays`) is what is timed.
+    Returns (ms, bytes received by the root, error or None)."""
+    import torch
+    from tracktolearn_amd.parallel import gather_tract_arrays, tract_arrays
+    try:
+        grp.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        moved = 0
+        if grp.world > 1:
+            got = gather_tract_arrays(env)
+            if got is not None:
+                moved = got[3]
+        else:
+            tract_arrays(env)
+        torch.cuda.synchronize()
+        grp.barrier()
+        return (time.perf_counter() - t1) * 1e3, moved, None
+    except Exception as exc:      # never lose the bench line to the collate
+        return None, None, repr(exc)
+
+
+def roofline_object(win, workload, mask_data, pmc_path, cache_note):
+    """The `roofline` object of a leg from its timed windows (rank 0's kernel
+    events) and the per-unit PMC bytes of `pmc_path`."""
+    w = WORKLOADS[workload]
+    k = w['n_dirs']
+    whole_b, kern_b = algorithmic_bytes(C, k)
+    steps = max(win['steps'], 1)
+    avg_launch_s = win['state_ms'] / max(win['state_n'], 1) * 1e-3
+    units_per_launch = win['rank0_units'] / steps
+    n_mask = int(np.count_nonzero(mask_data))
+    comp_b = compulsory_bytes(C, k, n_mask, units_per_launch)
+    pmc, pmc_src, kernel = None, None, DOMINANT_KERNEL
+    for path in pmc_path:
+        full = os.path.join(ROOT, 'profiles', path)
+        if not os.path.exists(full):
+            continue
+        try:
+            js = json.load(open(full))
+            pmc = js.get('k_state_hbm_bytes_per_unit')
+            kernel = js.get('k_state_kernel', kernel)
+            pmc_src = (f"profiles/{path} <- {js.get('source')}: PMC FETCH_SIZE/WRITE_SIZE "
+                       f"passes of this command (`--legs` restricted to this leg), "
+                       f"(2*FETCH+WRITE)*1024 bytes per unit x this run's units per "
+                       f"launch; NOT measured in this run.  {cache_note}")
+            break
+        except Exception:
+            pmc = None
+    if not avg_launch_s:
+        return None
+    traffic = pmc * units_per_launch if pmc else None
+    achieved = traffic / avg_launch_s / 1e9 if traffic else None
+    return {
+        'bound': 'hbm', 'kernel': kernel,
+        # HBM bytes per launch (PMC counters) / measured launch time
+        'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
+        'traffic': traffic,
+        'traffic_bytes_per_unit': pmc,
+        'traffic_source': pmc_src,
+        # what an ideal kernel must move (rows once + per-streamline
+        # inputs + every in-mask SH record once per launch)
+        'compulsory_bytes_per_unit': comp_b,
+        'compulsory_GBs': comp_b * units_per_launch / avg_launch_s / 1e9,
+        'compulsory_frac': comp_b * units_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+        # SURVEY 8(d): all 56 corner fetches charged per unit -- an
+        # upper bound on naive traffic, not a roofline fraction
+        'algorithmic_bytes_per_unit': kern_b,
+        'algorithmic_GBs': kern_b * units_per_launch / avg_launch_s / 1e9,
+        'units_per_launch': units_per_launch,
+        'avg_launch_ms': avg_launch_s * 1e3,
+        'launches': win['state_n'],
+        'whole_step_algorithmic_bytes_per_unit': whole_b,
+        'workload': w['what'],
+    }
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -279,12 +554,17 @@ def main(argv=None):
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--windows', type=int, default=11,
                     help='timed windows of --steps steps each (median reported)')
+    ap.add_argument('--legs', default='all',
+                    help='comma list of ' + ','.join(LEGS) + ' (default: all)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-whole-episode', action='store_true',
                     help='skip the episode-to-exhaustion figure (SURVEY 8d (ii))')
     ap.add_argument('--whole-episode', action='store_true',
                     help='(default now; kept for older command lines)')
     args = ap.parse_args(argv)
+    legs = set(LEGS) if args.legs == 'all' else set(args.legs.split(','))
+    if not legs <= set(LEGS):
+        sys.exit(f'--legs: unknown leg in {sorted(legs)} (known: {LEGS})')
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         return self_launch(args, argv)
@@ -295,7 +575,9 @@ def main(argv=None):
     if world != args.gpus:
         sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
-    subject = make_subject()
+    need_c2 = bool(legs & {'weak', 'strong'})
+    need_c4 = bool(legs & {'config4', 'hbm'})
+    subject = make_subject('c2') if need_c2 or not args.no_cpu_baseline else None
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         # before the first GPU call of this process (forked workers)
@@ -318,236 +600,210 @@ def main(argv=None):
             dist.init_process_group('nccl', device_id=torch.device(device))
         else:
             dist.init_process_group(backend)
-    red_dev = device if backend == 'nccl' else 'cpu'
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    env = make_env(subject, device, seed_offset=rank)
+    grp = Dist(world, device if backend == 'nccl' else 'cpu')
     seed = 1 + rank
-
-    # ---- warm-up on its own episode -------------------------------------
-    counter = {'state': env.reset(0, N_ACTOR), 'step': 0, 'resets': 0}
-    run_steps(env, args.warmup, seed, counter)
-    # exercise the periodic re-sort of the processing order once outside the
-    # timed regions
-    if env._n_active:
-        env._refresh_processing_order(force=True)
-    torch.cuda.synchronize()
-
-    # ---- timed windows: each EXACTLY --steps steps from a fresh reset ------
-    # The dominant kernel is bracketed with HIP events in every second window
-    # only: an event record costs ~6 us of GPU idle time on either side of the
-    # kernel (rocprofv3 trace, benchmarks/trace_gaps.py), ~5 % of a step.  All
-    # windows are timed alike and `value` is the median over all of them.
-    n_win = max(1, args.windows)
-    times, n_units, resets = [], 0, 0
-    state_ms, state_n, evented = 0.0, 0, []
-    for w in range(n_win):
-        counter = {'state': env.reset(0, N_ACTOR), 'step': 0, 'resets': 0}
-        with_events = (w % 2 == 1) or n_win == 1
-        if with_events:
-            env.profile_begin(max_launches=args.steps + 8, classes=('state',))
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n_units = run_steps(env, args.steps, seed, counter)
-        torch.cuda.synchronize()
-        barrier()
-        times.append(time.perf_counter() - t0)
-        resets = max(resets, counter['resets'])
-        if with_events:
-            ms, cnt = env.profile_end()['state']
-            state_ms += ms
-            state_n += cnt
-            evented.append(w)
-
-    # untimed replay of the same steps with every kernel class bracketed, for
-    # the per-kernel breakdown (the timed windows only bracket the dominant
-    # kernel to keep the event records out of the other launch gaps)
-    counter2 = {'state': env.reset(0, N_ACTOR), 'step': 0, 'resets': 0}
-    env.profile_begin(max_launches=max(16, args.steps + 8),
-                      classes=('advance', 'prefix', 'state'))
-    run_steps(env, args.steps, seed, counter2)
-    torch.cuda.synchronize()
-    prof_all = env.profile_end()
-
-    # ---- whole episode to exhaustion, outside the K-step
-    # windows of the contract ------------------------------------------------
-    ep = None
     free_tail = os.environ.get('TTL_BENCH_FREE_TAIL', '1') != '0'
-    if not args.no_whole_episode:
-        # two episodes, the second one reported (the first one of a process
-        # runs slower: allocator growth and first-use effects a tracking run
-        # pays once, on its first seed batch)
-        for attempt in range(2):
-            state = env.reset(0, N_ACTOR)
-            torch.cuda.synchronize()
-            t_ep = time.perf_counter()
-            ep_units, ep_steps, free_steps = 0, 0, 0
-            while env._n_active:
-                if free_tail and env.freerun_supported():
-                    # from 16 384 rows down a step is bound by the host waiting
-                    # for its survivor count: free-running steps, launched for
-                    # the newest count the GPU has reported, never waited for
-                    left = env._n_active
-                    _, free_steps = env.run_free_eager(
-                        lambda st: env.scripted_actions_free(st, seed, WOBBLE), state)
-                    ep_steps += free_steps
-                    break
-                ep_units += env._n_active
-                actions = env.scripted_actions(state, ep_steps, seed, WOBBLE)
-                env.step_device(actions)
-                state, _ = env.harvest()
-                ep_steps += 1
-            torch.cuda.synchronize()
-            t_ep = time.perf_counter() - t_ep
-            # streamline-steps = points added = sum(lengths - 1)
-            ep_units = int(env._buf_lengths[:N_ACTOR].sum().item()) - N_ACTOR
-            first = ep
-            ep = {'streamline_steps_per_s_rank0': ep_units / t_ep, 'steps': ep_steps,
-                  'streamline_steps': ep_units, 'ms': t_ep * 1e3,
-                  'free_running_tail_steps': free_steps,
-                  'order_refresh_every': env.SPATIAL_ORDER_REFRESH}
-            if first is not None:
-                ep['first_episode_ms'] = first['ms']
+    n_win = max(1, args.windows)
+    # rehearsals on small boxes may shrink config 4 (never the driver's runs)
+    c4_total = int(os.environ.get('TTL_BENCH_C4_TOTAL', WORKLOADS['c4']['n_total']))
 
-    # ---- collate finished tracts on rank 0 (the path's only exchange) ------
-    collate_ms, collate_bytes, collate_error = None, None, None
-    if world > 1:
-        try:
-            from tracktolearn_amd.parallel import gather_tract_arrays
-            barrier()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            got = gather_tract_arrays(env)
-            torch.cuda.synchronize()
-            barrier()
-            collate_ms = (time.perf_counter() - t1) * 1e3
-            if got is not None:
-                collate_bytes = got[3]
-        except Exception as exc:      # never lose the bench line to the collate
-            collate_error = repr(exc)
+    line = {
+        'metric': 'streamline-steps/s at n_actor=262144',
+        'value': None, 'unit': 'streamline-steps/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+    }
+    out = {}          # rank 0 assembles the line from this at the end
 
-    t_win = torch.tensor(times, dtype=torch.float64, device=red_dev)
-    units = torch.tensor([float(n_units)], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t_win, op=dist.ReduceOp.MAX)      # per window, over ranks
-        dist.all_reduce(units, op=dist.ReduceOp.SUM)
-    t_all = t_win.cpu().numpy()          # per window, max over the ranks
-    t_win = np.sort(t_all)
-    total_units = float(units.item())        # of ONE window, all ranks
-    t_med = float(t_win[len(t_win) // 2])
+    # ======================= 96^3 volume: weak + strong ====================
+    if need_c2:
+        from tracktolearn_amd.utils.synthetic import synthetic_seeds
+        env = make_env(subject, device, 'c2')
+        mask_c2 = subject[1].data
+        if 'weak' in legs:
+            env.seeds = synthetic_seeds(mask_c2, N_ACTOR, seed=100 + rank)
+            weak = timed_windows(env, N_ACTOR, args.steps, args.warmup, n_win, seed, grp)
+            weak['steps'] = args.steps
+            weak['other_kernels_ms_per_step'] = kernel_breakdown(env, N_ACTOR, args.steps, seed)
+            if not args.no_whole_episode:
+                weak['whole_episode'] = whole_episode(env, N_ACTOR, seed, free_tail)
+            if world > 1:
+                weak['collate'] = collate(env, grp)
+            out['weak'] = weak
+        if 'strong' in legs:
+            if world == 1 and 'weak' in out:
+                # one rank: the shard IS the whole batch -- the same run
+                strong = dict(out['weak'], same_run_as_value=True)
+            else:
+                env.seeds = shard_seeds(mask_c2, N_ACTOR, rank, world)
+                rows = len(env.seeds)
+                strong = timed_windows(env, rows, args.steps, args.warmup, n_win, seed, grp)
+                strong['rows_rank0'] = rows
+            out['strong'] = strong
+        out['placement'] = (getattr(env, '_sh_tuned', None),
+                            getattr(env, '_placement_search', None))
+        del env
+        torch.cuda.empty_cache()
+
+    # ======================= 145^3 volume: config 4 + HBM regime ===========
+    if need_c4:
+        from tracktolearn_amd.utils.synthetic import synthetic_seeds
+        t_setup = time.perf_counter()
+        subject4 = make_subject('c4')
+        mask_c4 = subject4[1].data
+        env4 = make_env(subject4, device, 'c4')
+        setup_s = time.perf_counter() - t_setup
+        from tracktolearn_amd.parallel import shard_bounds
+        lo, hi = shard_bounds(c4_total, rank, world)
+        rows4 = hi - lo
+        hbm = None
+        if 'hbm' in legs and not ('config4' in legs and rows4 == HBM_LEG_ROWS):
+            # the shard a GPU holds at N = 8, first: its reset is what places
+            # the volume and the ring of state buffers
+            env4.seeds = synthetic_seeds(mask_c4, HBM_LEG_ROWS, seed=100 + rank)
+            hbm = timed_windows(env4, HBM_LEG_ROWS, args.steps, args.warmup, n_win, seed, grp)
+            hbm['steps'] = args.steps
+        if 'config4' in legs:
+            env4.seeds = shard_seeds(mask_c4, c4_total, rank, world)
+            c4 = timed_windows(env4, rows4, args.steps, args.warmup, n_win, seed, grp)
+            c4['steps'] = args.steps
+            c4['rows_rank0'] = rows4
+            if 'hbm' in legs and hbm is None:
+                hbm = c4
+            # one whole tractogram end to end: track every streamline to
+            # exhaustion, then collate on rank 0 -- timed as one region
+            warm = whole_episode(env4, rows4, seed, free_tail, grp)
+            grp.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ep_steps, _ = track_to_exhaustion(env4, env4.reset(0, rows4), seed, free_tail)
+            torch.cuda.synchronize()
+            t_track = time.perf_counter() - t0
+            c_ms, c_bytes, c_err = collate(env4, grp)
+            t_total = time.perf_counter() - t0
+            ep_units = int(env4._buf_lengths[:rows4].sum().item()) - rows4
+            units = float(grp.reduce([ep_units], 'sum')[0])
+            t_track_max = float(grp.reduce([t_track], 'max')[0])
+            t_total_max = float(grp.reduce([t_total], 'max')[0])
+            c4['end_to_end'] = {
+                'what': 'reset -> every streamline tracked to exhaustion (scripted policy) '
+                        '-> finished tracts collated on rank 0; one timed region, max '
+                        'over ranks',
+                'streamline_steps': units, 'episode_steps_rank0': ep_steps,
+                'track_ms': t_track_max * 1e3, 'collate_ms': c_ms,
+                'collate_bytes_to_root': c_bytes, 'end_to_end_ms': t_total_max * 1e3,
+                'value_step_only': units / t_track_max,
+                'value_end_to_end': units / t_total_max,
+                'warm_episode_rank0': warm,
+            }
+            if c_err:
+                c4['end_to_end']['collate_error'] = c_err
+            if world == 1:
+                c4['end_to_end']['collate'] = ('one rank: nothing to exchange; collate_ms '
+                                               'is the device-side ragged pack of the tracts')
+            out['config4'] = c4
+        if hbm is not None:
+            out['hbm'] = hbm
+        out['c4_setup_s'] = setup_s
+        out['c4_placement'] = (getattr(env4, '_sh_tuned', None),
+                               getattr(env4, '_placement_search', None))
+        out['mask_c4'] = mask_c4
 
     if rank == 0:
-        whole_b, kern_b = algorithmic_bytes(C, N_DIRS)
-        adv_ms, adv_n = prof_all['advance']
-        pre_ms, _ = prof_all['prefix']
-        avg_launch_s = state_ms / max(state_n, 1) * 1e-3
-        units_per_launch = n_units / max(args.steps, 1)
-        algorithmic_gbs = kern_b * units_per_launch / avg_launch_s / 1e9
-        n_mask = int(np.count_nonzero(subject[1].data))
-        comp_b = compulsory_bytes(C, N_DIRS, n_mask, units_per_launch)
-        pmc, pmc_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                js = json.load(open(tpath))
-                pmc = js.get('k_state_hbm_bytes_per_unit')
-                pmc_src = (f"profiles/pmc_traffic.json <- {js.get('source')}: PMC "
-                           f"FETCH_SIZE/WRITE_SIZE passes of this command, "
-                           f"(2*FETCH+WRITE)*1024 bytes per unit x this run's units "
-                           f"per launch; NOT measured in this run")
-            except Exception:
-                pmc = None
-        traffic = pmc * units_per_launch if pmc else None
-        achieved = traffic / avg_launch_s / 1e9 if traffic else None
-        value = total_units / t_med
-        line = {
-            'metric': 'streamline-steps/s at n_actor=262144',
-            'value': value,
-            'unit': 'streamline-steps/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': t_med / args.steps * 1e3,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f32',
-            'data': 'synthetic',
-            'config': {
-                'workload': 'env.step only (scripted actions -> step -> '
-                            'harvest), 96^3x45-SH synthetic volume, '
-                            'n_actor=262144 per GPU, 1xMI355X per rank',
-                'n_actor_per_gpu': N_ACTOR, 'volume': [D, D, D, C],
-                'n_dirs': N_DIRS, 'state_width': 7 * C + 3 * N_DIRS,
-                'reward': False, 'arithmetic': 'float32 directions (train env)',
-                'loop': 'step_device + harvest (survivors-first rows, 8-byte '
-                        'count readback per step)',
-                'resets_in_timed_region': resets,
-                'parallelism': f'streamlines sharded over {world} GPU(s), '
-                               'volumes replicated',
-            },
-            'streamline_steps': total_units,
-            'windows': {
-                'n': len(t_win), 'timed': 'each window = exactly --steps steps '
-                'from a fresh untimed reset; value/ms_per_step = median window',
-                'with_kernel_events': evented,
-                'value_median_with_events': (total_units / float(np.median(
-                    [t_all[i] for i in evented]))) if evented else None,
-                'value_median_without_events': (total_units / float(np.median(
-                    [t_all[i] for i in range(len(t_all)) if i not in evented])))
-                if len(evented) < len(t_all) else None,
-                'value_min': total_units / float(t_win[-1]),
-                'value_median': value,
-                'value_max': total_units / float(t_win[0]),
-                'ms_per_step_min': float(t_win[0]) / args.steps * 1e3,
-                'ms_per_step_max': float(t_win[-1]) / args.steps * 1e3,
-            },
-            'roofline': {
-                'bound': 'hbm', 'kernel': DOMINANT_KERNEL,
-                # HBM bytes per launch (PMC counters) / measured launch time
-                'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': (achieved / HBM_PEAK_GBS) if achieved else None,
-                'traffic': traffic,
-                'traffic_bytes_per_unit': pmc,
-                'traffic_source': pmc_src,
-                # what an ideal kernel must move (rows once + per-streamline
-                # inputs + every in-mask SH record once per launch)
-                'compulsory_bytes_per_unit': comp_b,
-                'compulsory_GBs': comp_b * units_per_launch / avg_launch_s / 1e9,
-                'compulsory_frac': comp_b * units_per_launch / avg_launch_s / 1e9
-                / HBM_PEAK_GBS,
-                # all 56 corner fetches charged per unit -- an
-                # upper bound on naive traffic, not a roofline fraction
-                'algorithmic_bytes_per_unit': kern_b,
-                'algorithmic_GBs': algorithmic_gbs,
-                'units_per_launch': units_per_launch,
-                'avg_launch_ms': avg_launch_s * 1e3,
-                'launches': state_n,
-                'whole_step_algorithmic_bytes_per_unit': whole_b,
-                'whole_step_algorithmic_GBs': whole_b * value / world / 1e9,
-                'other_kernels_ms_per_step': {
-                    'advance': adv_ms / max(adv_n, 1),
-                    'prefix': pre_ms / max(adv_n, 1)},
-            },
+        note_c2 = ('FETCH_SIZE counts Infinity-Cache hits: the 170 MB packed 96^3 volume '
+                   'fits the 256 MB cache, so this is fabric traffic, of which the read '
+                   'share is mostly cache-served, not DRAM traffic (see '
+                   'roofline_hbm_regime for a volume that does not fit).')
+        note_c4 = ('The 585 MB packed 145^3 volume does not fit the 256 MB Infinity '
+                   'Cache: reads go to HBM.')
+        weak = out.get('weak')
+        head = weak or out.get('strong') or out.get('config4') or out.get('hbm')
+        if weak:
+            line['value'] = weak['value']
+            line['ms_per_step'] = weak['ms_per_step']
+        line['config'] = {
+            'workload': 'env.step only (scripted actions -> step -> '
+                        'harvest), 96^3x45-SH synthetic volume, '
+                        'n_actor=262144 per GPU, 1xMI355X per rank',
+            'n_actor_per_gpu': N_ACTOR, 'volume': [D, D, D, C],
+            'n_dirs': N_DIRS, 'state_width': 7 * C + 3 * N_DIRS,
+            'reward': False, 'arithmetic': 'float32 directions (train env)',
+            'loop': 'step_device + harvest (survivors-first rows, 8-byte '
+                    'count readback per step)',
+            'resets_in_timed_region': weak['resets'] if weak else None,
+            'parallelism': f'streamlines sharded over {world} GPU(s), '
+                           'volumes replicated',
+            'legs': sorted(legs),
         }
-        if ep is not None:
-            line['whole_episode'] = ep
-        if getattr(env, '_sh_tuned', None):
-            # gather time (ms per launch at 131 072 streamlines) of every pair
-            # (allocation of the SH volume, allocation of the state ring) tried at the
-            # first large reset; the fastest pair was kept (env.py:_tune_placement)
-            line['placement_candidates_ms'] = env._sh_tuned
-        if collate_ms is not None:
-            line['collate_ms'] = collate_ms
-            line['collate_bytes_to_root'] = collate_bytes
-        if collate_error is not None:
-            line['collate_error'] = collate_error
+        if weak:
+            line['streamline_steps'] = weak['streamline_steps']
+            line['windows'] = weak['windows']
+            roof = roofline_object(weak, 'c2', subject[1].data, ['pmc_traffic.json'], note_c2)
+            if roof is not None:
+                roof['whole_step_algorithmic_GBs'] = \
+                    roof['whole_step_algorithmic_bytes_per_unit'] * weak['value'] / world / 1e9
+                roof['other_kernels_ms_per_step'] = weak['other_kernels_ms_per_step']
+            line['roofline'] = roof
+            if weak.get('whole_episode'):
+                line['whole_episode'] = weak['whole_episode']
+            if 'collate' in weak:
+                line['collate_ms'], line['collate_bytes_to_root'] = weak['collate'][:2]
+                if weak['collate'][2]:
+                    line['collate_error'] = weak['collate'][2]
+        if 'strong' in out:
+            s = out['strong']
+            line['strong'] = {
+                'what': 'BASELINE metric as stated: 262144 streamlines in TOTAL, one global '
+                        'seed batch sharded contiguously over the ranks '
+                        '(parallel.shard_bounds), same 96^3 volume and loop as `value`',
+                'scaling': 'strong', 'n_actor_total': N_ACTOR,
+                'n_actor_per_gpu': -(-N_ACTOR // world),
+                'value': s['value'], 'ms_per_step': s['ms_per_step'],
+                'streamline_steps': s['streamline_steps'],
+                'value_min': s['windows']['value_min'], 'value_max': s['windows']['value_max'],
+                'windows': s['windows']['n'],
+                'same_run_as_value': bool(s.get('same_run_as_value', False)),
+            }
+        if 'config4' in out:
+            c4 = out['config4']
+            line['config4'] = {
+                'what': 'BASELINE configs[3] on synthetic data: ' + WORKLOADS['c4']['what']
+                        + f', {c4_total} streamlines in total sharded over {world} GPU(s)',
+                'scaling': 'strong', 'n_actor_total': c4_total,
+                'n_actor_per_gpu': -(-c4_total // world),
+                'step_only': {'value': c4['value'], 'ms_per_step': c4['ms_per_step'],
+                              'streamline_steps': c4['streamline_steps'],
+                              'value_min': c4['windows']['value_min'],
+                              'value_max': c4['windows']['value_max'],
+                              'windows': c4['windows']['n'], 'steps': args.steps},
+                'end_to_end': c4['end_to_end'],
+                'setup_s': out['c4_setup_s'],
+            }
+        if 'hbm' in out:
+            roof4 = roofline_object(out['hbm'], 'c4', out['mask_c4'],
+                                    ['pmc_traffic_c4shard.json',
+                                     'r02_c4shard_pmc_traffic.json'], note_c4)
+            if roof4 is not None:
+                roof4['value_rank0_shard'] = out['hbm']['rank0_units'] / \
+                    (out['hbm']['ms_per_step'] * 1e-3 * args.steps)
+                roof4['ms_per_step'] = out['hbm']['ms_per_step']
+            line['roofline_hbm_regime'] = roof4
+        tuned, search = out.get('placement', (None, None))
+        if tuned:
+            # gather time (ms per launch) of every pair (allocation of the SH
+            # volume, allocation of a state buffer) tried at the first large
+            # reset; the fastest pair was kept (env.py:_tune_placement)
+            line['placement_candidates_ms'] = tuned
+        if search:
+            line['placement_search'] = search
+        if out.get('c4_placement', (None, None))[1]:
+            line['placement_search_config4'] = out['c4_placement'][1]
         if not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu
+            line['cpu_baseline'] = cpu if world == 1 else \
+                'N=1 only (the oracle is timed on rank 0 of a 1-GPU run)'
+        if head is None:
+            line['error'] = 'no leg ran'
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

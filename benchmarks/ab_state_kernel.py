@@ -40,9 +40,9 @@ def make(variant, subject):
     d = int(cfg['d'])
     if d != 96:          # another volume size (cache-residency experiments)
         if d not in _SUBJECTS:
-            bench.D = d
-            _SUBJECTS[d] = bench.make_subject()
-            bench.D = 96
+            from tracktolearn_amd.utils.synthetic import synthetic_subject
+            _SUBJECTS[d] = synthetic_subject(d, bench.C, seed=1234, peaks=False,
+                                             affine_dtype=np.float32)
         subject = _SUBJECTS[d]
     os.environ['TTL_STATE_KERNEL'] = cfg['k']
     os.environ['TTL_LOCAL_SORT'] = cfg['ls']
@@ -51,7 +51,9 @@ def make(variant, subject):
     os.environ['TTL_STORE_FLAVOUR'] = cfg['st']
     os.environ['TTL_CONTIGUOUS_VOLUME'] = cfg['cv']
     os.environ['TTL_VOLUME_CANDIDATES'] = cfg['vc']
-    env = bench.make_env(subject, 'cuda:0', 0)
+    from tracktolearn_amd.utils.synthetic import synthetic_seeds
+    env = bench.make_env(subject, 'cuda:0', 'c2')
+    env.seeds = synthetic_seeds(subject[1].data, bench.N_ACTOR, seed=100)
     env.SPATIAL_ORDER_REFRESH = int(cfg['r'])
     env._fine = cfg['fine']
     env.reset(0, 64)                     # creates the handle (reads the variables)
@@ -66,7 +68,7 @@ def window(env, steps=12):
     counter = {'state': env.reset(0, bench.N_ACTOR), 'step': 0, 'resets': 0}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = bench.run_steps(env, steps, 1, counter)
+    n = bench.run_steps(env, steps, 1, counter, bench.N_ACTOR)
     torch.cuda.synchronize()
     return n, time.perf_counter() - t0
 

@@ -13,11 +13,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
+from benchmarks.placement_probe import make_bench_env  # noqa: E402
 
 
 def main():
     subject = bench.make_subject()
-    env = bench.make_env(subject, 'cuda:0', 0)
+    env = make_bench_env(subject)
     for rep in range(2):
         state = env.reset(0, bench.N_ACTOR)
         torch.cuda.synchronize()

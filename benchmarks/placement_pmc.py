@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 os.environ['TTL_VOLUME_CANDIDATES'] = '1'
 import bench  # noqa: E402
 from benchmarks.ab_state_kernel import window  # noqa: E402
-from benchmarks.placement_probe import timed  # noqa: E402
+from benchmarks.placement_probe import make_bench_env, timed  # noqa: E402
 
 LAUNCHES = [0]
 
@@ -32,7 +32,7 @@ def main():
     subject = bench.make_subject()
     envs, times = [], []
     for i in range(10):
-        env = bench.make_env(subject, 'cuda:0', 0)
+        env = make_bench_env(subject)
         env.reset(0, bench.N_ACTOR)
         LAUNCHES[0] += 1
         counted_window(env)

@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
-"""Why do env instances of one process gather at 0.176 or at 0.20 ms?  Creates
-instances of bench.py's env with allocator churn in between, prints the device
-addresses of their large buffers next to the gather's launch time, then moves
-single buffers of one instance to fresh allocations (same contents) to see which
-allocation the time follows.
+"""Where the gather's source and destination land in device memory.
+One parametrised script (round 3; rounds 1-2 kept sixteen near-duplicates,
+`placement_probe2.py` .. `placement_probe16.py` -- git history before round 3 --
+whose findings are recorded in DESIGN.md 3.3 and under profiles/r02_placement_*):
 
-    python benchmarks/placement_probe.py [instances]
+    python benchmarks/placement_probe.py instances [n]
+        env instances of one process gather at 0.176 or at 0.20 ms: creates n
+        instances of bench.py's env with allocator churn in between, prints the
+        device addresses of their large buffers next to the gather's launch time,
+        then moves single buffers of the slowest instance to fresh allocations
+        (same contents) to see which allocation the time follows.
+    python benchmarks/placement_probe.py pairs [kind]
+        the pair matrix: five allocations of the packed SH volume x five of a
+        ring of state buffers (kind 0 hipMalloc, 1 contiguous, 2 virtual-memory
+        API), the gather's time for every pair.
 """
 import json
 import os
@@ -63,8 +71,14 @@ def rehandle(env):
     window(env)
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+def make_bench_env(subject):
+    from tracktolearn_amd.utils.synthetic import synthetic_seeds
+    env = bench.make_env(subject, 'cuda:0', 'c2')
+    env.seeds = synthetic_seeds(subject[1].data, bench.N_ACTOR, seed=100)
+    return env
+
+
+def instances(n=6):
     rng = np.random.RandomState(0)
     subject = bench.make_subject()
     envs, junk = [], []
@@ -73,7 +87,7 @@ def main():
         junk.append(torch.empty(int(rng.randint(1, 400)) << 20, dtype=torch.uint8, device='cuda:0'))
         if i % 2:
             junk.pop(0)
-        env = bench.make_env(subject, 'cuda:0', 0)
+        env = make_bench_env(subject)
         env.reset(0, bench.N_ACTOR)
         window(env)
         envs.append(env)
@@ -109,5 +123,44 @@ def main():
         print(json.dumps(dict(i=i, final_ms=round(timed(env), 4), ref=reference_kernel_ms())), flush=True)
 
 
+def pairs(kind=0):
+    """Is the placement effect of the SH volume independent of that of the state
+    rows?  Five volume allocations x five ring allocations (fresh allocations
+    each), the gather's time for every pair."""
+    from tracktolearn_amd import _lib
+    os.environ['TTL_VOLUME_CANDIDATES'] = '1'
+    subject = bench.make_subject()
+    env = make_bench_env(subject)
+    env.reset(0, bench.N_ACTOR)
+    window(env)
+    own = env._sh_packed
+    nbytes = own.numel() * 4
+    W, P, N = env._state_width, env._state_pitch, bench.N_ACTOR
+    vols, rings, keep = [], [], []
+    for k in range(5):
+        mem = _lib.DeviceVolume(0, nbytes, kind)
+        vol = torch.as_tensor(mem, device='cuda:0').view(torch.float32).view(own.shape)
+        vol.copy_(own)
+        vols.append(vol)
+        keep.append(mem)
+        mem = _lib.DeviceVolume(0, 4 * N * P * 4, kind)
+        flat = torch.as_tensor(mem, device='cuda:0').view(torch.float32)
+        rings.append([flat[i * N * P:(i + 1) * N * P].view(N, P)[:, :W] for i in range(4)])
+        keep.append(mem)
+    for vi, vol in enumerate(vols):
+        row = []
+        env._sh_packed = vol
+        for ring in rings + [None]:
+            env._state_ring, env._state_ring_pos = ring, 0
+            rehandle(env)
+            row.append(round(timed(env, rounds=2), 4))
+        print(json.dumps(dict(volume=vi, ptr=hex(vol.data_ptr()), gather_ms_by_ring=row[:-1],
+                              allocator_rows_ms=row[-1])), flush=True)
+    print(json.dumps(dict(kind=kind, granted=[m.contiguous for m in keep[:2]],
+                          ring_ptrs=[hex(r[0].data_ptr()) for r in rings])), flush=True)
+
+
 if __name__ == '__main__':
-    main()
+    what = sys.argv[1] if len(sys.argv) > 1 else 'instances'
+    arg = [int(a) for a in sys.argv[2:3]]
+    {'instances': instances, 'pairs': pairs}[what](*arg)

@@ -382,13 +382,17 @@ def test_bench_self_launch_reports_failed_ranks():
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """The N > 1 path of bench.py as far as a 1-GPU box can take it: the bare
     `--gpus 2` call launches two ranks itself (both on cuda:0, gloo instead of
-    RCCL, which refuses two ranks on one device), shards, times the windows,
-    gathers the finished tracts to rank 0 and prints ONE line."""
+    RCCL, which refuses two ranks on one device), shards, times the windows of
+    every leg, gathers the finished tracts to rank 0 and prints ONE line that
+    carries the weak-scaling value, the strong-scaling leg (262144 streamlines
+    in total) and config 4 (145^3, sharded, collate included end to end).
+    Config 4 is shrunk to 262144 streamlines in total for the rehearsal: the
+    shard is then the 131072 rows one GPU holds at N = 8."""
     env = dict(os.environ, PYTHONPATH=ROOT, TTL_BENCH_ONE_DEVICE='1',
-               TTL_BENCH_BACKEND='gloo')
+               TTL_BENCH_BACKEND='gloo', TTL_BENCH_C4_TOTAL='262144')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
                           '--windows', '3', '--no-cpu-baseline'],
-                         capture_output=True, text=True, timeout=900, env=env)
+                         capture_output=True, text=True, timeout=1100, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = _last_json_line(out.stdout)
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak'
@@ -397,3 +401,22 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert 'collate_error' not in line
     assert line['windows']['n'] == 3
     assert line['roofline']['frac'] is None or line['roofline']['frac'] <= 1.0
+    # strong scaling: one global batch of 262144 seeds split over the two ranks
+    strong = line['strong']
+    assert strong['scaling'] == 'strong' and strong['n_actor_total'] == 262144
+    assert strong['n_actor_per_gpu'] == 131072 and not strong['same_run_as_value']
+    assert 12 * 200000 < strong['streamline_steps'] <= 12 * 262144
+    assert strong['value'] > 0
+    # config 4: sharded 145^3 run, the collate inside the end-to-end figure
+    c4 = line['config4']
+    assert c4['n_actor_total'] == 262144 and c4['n_actor_per_gpu'] == 131072
+    assert c4['step_only']['value'] > 0
+    e2e = c4['end_to_end']
+    assert 'collate_error' not in e2e
+    assert e2e['collate_ms'] > 0 and e2e['collate_bytes_to_root'] > 0
+    assert e2e['end_to_end_ms'] >= e2e['track_ms'] + 0.5 * e2e['collate_ms']
+    assert 0 < e2e['value_end_to_end'] < e2e['value_step_only']
+    # every streamline of both shards was tracked to exhaustion
+    assert e2e['streamline_steps'] > 262144 * 10
+    assert line['roofline_hbm_regime']['units_per_launch'] > 100000
+    assert line['cpu_baseline'].startswith('N=1 only') if 'cpu_baseline' in line else True

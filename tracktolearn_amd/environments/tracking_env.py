@@ -646,6 +646,9 @@ class TrackingEnvironment(BaseEnv):
             'ttl_env_freerun_scripted_actions')
         return out
 
+    #: kernel classes `profile_begin` can bracket (ttl_env_profile_begin's mask bits)
+    PROFILE_CLASSES = ('advance', 'prefix', 'state')
+
     def profile_begin(self, max_launches=4096, classes=('state',)):
         """Bracket the step kernels of the given classes ('advance', 'prefix',
         'state') with HIP events on the launch stream."""
