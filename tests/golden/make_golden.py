@@ -4,6 +4,10 @@ classes, imported read-only from /root/reference in the build container.
 
 Run:  python tests/golden/make_golden.py         (only where /root/reference
 exists; the GPU box never sees the reference, only the .npz files travel).
+Every trace seeds its own seed stream (`seed_stream`), so each fixture is
+reproduced byte for byte by this script whatever traces are added or removed
+around it; tests/test_golden_reproducible.py checks that for all four
+generators wherever the reference tree is present.
 
 How the reference is made importable: its third-party
 imports that are absent from this image (nibabel, dipy, dwi_ml, scilpy, h5py,
@@ -235,7 +239,9 @@ def _save(name, out):
     out['versions'] = np.array(
         [f'numpy {np.__version__}', f'scipy {scipy.__version__}',
          f'torch {torch.__version__}'])
-    path = os.path.join(HERE, name + '.npz')
+    # TTL_GOLDEN_OUT: write somewhere else (tests/test_golden_reproducible.py
+    # regenerates every fixture into a scratch directory and compares)
+    path = os.path.join(os.environ.get('TTL_GOLDEN_OUT') or HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
 
@@ -311,8 +317,8 @@ def isolated(ref):
 
 
 def extra_traces(ref):
-    """Traces added after the first set; each seeds its own seed stream, so
-    `python make_golden.py extra` regenerates them alone, byte for byte."""
+    """Traces added after the first set (`python make_golden.py extra`
+    regenerates them alone)."""
     # 2 mm isotropic voxels and an origin offset (files-style float64 affine):
     # pins convert_length_mm2vox / step size / neighbourhood radius in voxels
     run_trace(ref, 'trace_f64_K4_vox2mm', D=16, N=96, K=4, noisy=True,
@@ -349,26 +355,27 @@ def main():
     # train env, float32 affine -> float32 direction arithmetic, reward on
     run_trace(ref, 'trace_f32_K4_reward', D=12, N=96, K=4, noisy=False,
               affine_dtype=np.float32, reward=True, max_length=6.0,
-              wobble=0.12)
+              wobble=0.12, seed_stream=971)
     # track env: noisy class, sigma 0, float64 affine -> float64 directions
     run_trace(ref, 'trace_f64_K100', D=10, N=48, K=100, noisy=True,
               affine_dtype=np.float64, reward=False, max_length=300.0,
-              wobble=0.10, state_every=4)
+              wobble=0.10, state_every=4, seed_stream=972)
     # larger batch: states recorded as row sums after step 2
     run_trace(ref, 'trace_f32_K4_n512', D=16, N=512, K=4, noisy=False,
               affine_dtype=np.float32, reward=False, max_length=60.0,
-              wobble=0.15, state_every=1000)
+              wobble=0.15, state_every=1000, seed_stream=973)
     # the shipped model's state: K = 100 with streamlines longer than 101
     # points, so the direction block is full and slides (96^3 volume, as
     # BASELINE config 2; near-diametral chords)
     run_trace(ref, 'trace_f64_K100_long', D=96, N=40, K=100, noisy=True,
               affine_dtype=np.float64, reward=False, max_length=300.0,
               wobble=0.02, state_every=100000, aim_centre=True,
-              state_steps=(99, 100, 101, 102, 103), keep_history=True)
+              state_steps=(99, 100, 101, 102, 103), keep_history=True,
+              seed_stream=974)
     # noisy class with float32 affine (HDF5 validation env), reward on
     run_trace(ref, 'trace_f64_K4_f32affine', D=12, N=64, K=4, noisy=True,
               affine_dtype=np.float32, reward=True, max_length=30.0,
-              wobble=0.2, state_every=2)
+              wobble=0.2, state_every=2, seed_stream=975)
     extra_traces(ref)
 
 
