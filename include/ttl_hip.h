@@ -41,7 +41,7 @@ extern "C" {
 #define TTL_API
 #endif
 
-#define TTL_ABI_VERSION 7
+#define TTL_ABI_VERSION 8
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -401,6 +401,17 @@ TTL_API int ttl_resample_streamlines(const float *points, int64_t row_pitch,
                              const int32_t *lengths32, const int64_t *lengths64,
                              int32_t n, int32_t max_len, int32_t nb_points, float *out,
                              void *hip_stream);
+
+/* Ragged pack of tracked streamlines (ABI v8), the device side of
+ * TrackingEnvironment.get_streamlines (tracking_env.py:263-284) and of the
+ * multi-GPU collate: history [n] rows of row_pitch floats (the env's
+ * `streamlines` buffer, row_pitch = 3 * (max_nb_steps + 1)); keep[i] points of
+ * row i (int64; lengths minus the point a CURVATURE / MASK stop drops) are
+ * copied to points_out + 3 * offsets[i] (offsets = exclusive prefix of keep,
+ * int64).  One wave per streamline, coalesced; device pointers. */
+TTL_API int ttl_pack_streamlines(const float *history, int64_t row_pitch, const int64_t *keep,
+                         const int64_t *offsets, int32_t n, float *points_out,
+                         void *hip_stream);
 
 TTL_API const char *ttl_last_error(void);
 TTL_API uint32_t ttl_abi_version(void);

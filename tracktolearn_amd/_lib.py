@@ -18,7 +18,7 @@ import torch  # noqa: F401  (keep above the CDLL below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 SH_LINEAR, SH_BRICK4 = 0, 1
 MODE_F32 = 0
 MODE_F64DIR = 1
@@ -129,6 +129,8 @@ SYMBOLS = {
     'ttl_resample_streamlines': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_void_p]),
+    'ttl_pack_streamlines': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_void_p, C.c_void_p]),
     'ttl_last_error': (C.c_char_p, []),
     'ttl_abi_version': (C.c_uint32, []),
     'ttl_env_desc_size': (C.c_size_t, []),

@@ -8,6 +8,7 @@ interchangeable.  The gaussian draw of the max-entropy actor can be injected
 (``eps=``) for known-answer tests.
 """
 import math
+import os
 from os.path import join as pjoin
 
 import numpy as np
@@ -29,7 +30,26 @@ def mlp_inference(layers, x):
     ``torch._addmm_activation``: the same bits as ``relu(linear(x))`` on this
     stack -- checked in tests -- and one launch less per hidden layer; a tracking
     step at a few hundred rows is bound by its launches).  Anything else in the
-    stack, or a build without that entry point, takes the ordinary path."""
+    stack, or a build without that entry point, takes the ordinary path.
+
+    ``TTL_POLICY_TILE_ROWS=R`` (off by default) evaluates the stack in tiles of
+    exactly R rows (the last one zero padded): every GEMM then has the same
+    shape whatever the batch size, so a row's action no longer depends on how
+    many other rows share its batch -- a tractogram tracked in shards (one seed
+    batch split over several GPUs, runners/ttl_track.py) is then identical to
+    the one-process tractogram bit for bit, at the price of the padding."""
+    tile = int(os.environ.get('TTL_POLICY_TILE_ROWS', '0') or 0)
+    if tile > 0 and x.dim() == 2 and not torch.is_grad_enabled():
+        n = x.shape[0]
+        pad = (-n) % tile
+        if pad:
+            x = torch.cat([x, x.new_zeros((pad, x.shape[1]))])
+        out = [_mlp_inference(layers, x[i:i + tile]) for i in range(0, n + pad, tile)]
+        return (out[0] if len(out) == 1 else torch.cat(out))[:n]
+    return _mlp_inference(layers, x)
+
+
+def _mlp_inference(layers, x):
     fused = getattr(torch, '_addmm_activation', None)
     if fused is None or x.dim() != 2 or torch.is_grad_enabled():
         return layers(x)

@@ -789,6 +789,20 @@ __global__ __launch_bounds__(BLOCK) void k_copy_rows(
     for (int f = sub; f < width; f += LPS) dst[f] = src[f];
 }
 
+// ragged pack of the tracked streamlines (tracking_env.py:263-284: the first
+// keep[i] points of streamline i, one after the other): one wave per streamline
+__global__ __launch_bounds__(BLOCK) void k_pack_streamlines(
+    const float *__restrict__ hist, long long row_pitch, const long long *__restrict__ keep,
+    const long long *__restrict__ offsets, int n, float *__restrict__ out) {
+    const int i = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int floats = (int)keep[i] * 3;
+    const float *src = hist + (size_t)i * (size_t)row_pitch;
+    float *dst = out + (size_t)offsets[i] * 3;
+    for (int f = lane; f < floats; f += 64) dst[f] = src[f];
+}
+
 __global__ __launch_bounds__(BLOCK) void k_reset(EnvParams P, int *idx,
                                                  const float *__restrict__ seeds,
                                                  int n) {
@@ -1899,6 +1913,19 @@ int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream) {
     if (rc == TTL_OK) rc = seg_init(env, env->proc_cur, env->n_active, (hipStream_t)hip_stream);
     if (rc == TTL_OK) env->use_proc = 1;
     return rc;
+}
+
+int ttl_pack_streamlines(const float *history, int64_t row_pitch, const int64_t *keep,
+                         const int64_t *offsets, int32_t n, float *points_out,
+                         void *hip_stream) {
+    if (!history || !keep || !offsets || !points_out || n < 1 || row_pitch < 3)
+        return fail(TTL_ERR_INVALID, "ttl_pack_streamlines: bad arguments");
+    const int per_block = BLOCK / 64;
+    hipLaunchKernelGGL(k_pack_streamlines, dim3((n + per_block - 1) / per_block), dim3(BLOCK), 0,
+                       (hipStream_t)hip_stream, history, (long long)row_pitch,
+                       (const long long *)keep, (const long long *)offsets, n, points_out);
+    HIP_TRY(hipGetLastError());
+    return TTL_OK;
 }
 
 int ttl_env_view(ttl_env *env, const int32_t **continue_idx,

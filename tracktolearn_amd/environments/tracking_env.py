@@ -700,10 +700,8 @@ class TrackingEnvironment(BaseEnv):
         cut = (StoppingFlags.STOPPING_CURVATURE.value |
                StoppingFlags.STOPPING_MASK.value)
         keep_len = lengths_dev - ((flags_dev & cut) != 0).to(torch.int64)
-        hist = self._buf_streamlines[:n]
-        steps = torch.arange(hist.shape[1], device=self.device)
-        valid = steps[None, :] < keep_len[:, None]
-        points = hist[valid].to('cpu').numpy()
+        from tracktolearn_amd.parallel import pack_points
+        points = pack_points(self._buf_streamlines[:n], keep_len).to('cpu').numpy()
         keep_len_np = keep_len.to('cpu').numpy()
         offsets = np.concatenate(([0], np.cumsum(keep_len_np)))
         stopped_streamlines = [points[offsets[i]:offsets[i + 1]]

@@ -39,10 +39,30 @@ def kept_lengths(lengths, flags):
 
 
 def pack_points(history, keep_len):
-    """Ragged pack on the device: (n, T, 3) history + kept lengths ->
-    (sum(keep_len), 3) points, streamline-major."""
-    steps = torch.arange(history.shape[1], device=history.device)
-    return history[steps[None, :] < keep_len[:, None]]
+    """Ragged pack: (n, T, 3) history + kept lengths -> (sum(keep_len), 3)
+    points, streamline-major.  On the GPU: one wave per streamline
+    (``ttl_pack_streamlines``; the boolean-mask indexing it replaces took
+    56 ms for the 68 M points of a 1 048 576-streamline tractogram, the kernel
+    moves them at memory speed).  Host tensors (the gloo tests) index."""
+    if not history.is_cuda:
+        steps = torch.arange(history.shape[1], device=history.device)
+        return history[steps[None, :] < keep_len[:, None]]
+    from tracktolearn_amd import _lib
+    from tracktolearn_amd.environments.env import _raw_stream
+    n = int(history.shape[0])
+    keep = keep_len.to(torch.int64).contiguous()
+    ends = torch.cumsum(keep, 0)
+    total = int(ends[-1].item()) if n else 0
+    out = torch.empty((total, 3), dtype=torch.float32, device=history.device)
+    if total:
+        hist = history if history.is_contiguous() else history.contiguous()
+        offsets = ends - keep
+        import ctypes as C
+        _lib.check(_lib.load().ttl_pack_streamlines(
+            hist.data_ptr(), hist.stride(0), keep.data_ptr(), offsets.data_ptr(), n,
+            out.data_ptr(), C.c_void_p(_raw_stream(history.device.index or 0))),
+            'ttl_pack_streamlines')
+    return out
 
 
 def all_gather_counts(values, group=None):
