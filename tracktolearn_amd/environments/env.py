@@ -578,6 +578,9 @@ class BaseEnv(object):
         self._row_dest_all = self._buf_ws[off:off + 4 * n_max].view(torch.int32)
         self._host_counts = torch.zeros(4, dtype=torch.int32).pin_memory()
         self._host_counts_np = self._host_counts.numpy()
+        # staging of the reference's host contract (step(numpy) -> host dones /
+        # reward), allocated at the first such step (TrackingEnvironment._host_io)
+        self._io = None
         self._n_continue_out = C.c_int32()
 
     # ------------------------------------------------------------------ #

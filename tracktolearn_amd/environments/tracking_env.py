@@ -206,14 +206,45 @@ class TrackingEnvironment(BaseEnv):
         return self._start(self.seeds[start:end])
 
     # ------------------------------------------------------------------ #
+    def _host_io(self):
+        """Persistent staging buffers of the reference's host contract
+        (``step(numpy actions)`` -> host ``reward`` / ``dones``): pinned host
+        memory for the action batch, the dones and the reward, the action
+        batch's device buffer, an event.  Pageable copies go through the
+        runtime's own staging buffers and block the host; these do not."""
+        if self._io is None:
+            n = self._n_max
+            io = dict(
+                act_pin=torch.empty((n, 3), dtype=torch.float32).pin_memory(),
+                act_dev=torch.empty((n, 3), dtype=torch.float32, device=self.device),
+                done_pin=torch.empty(n, dtype=torch.uint8).pin_memory(),
+                reward_pin=torch.empty(n, dtype=torch.float64).pin_memory()
+                if self.compute_reward else None,
+                event=torch.cuda.Event())
+            io['act_np'] = io['act_pin'].numpy()
+            io['done_np'] = io['done_pin'].numpy()
+            io['reward_np'] = io['reward_pin'].numpy() if io['reward_pin'] is not None else None
+            self._io = io
+        return self._io
+
     def _actions_to_device(self, actions):
         if isinstance(actions, torch.Tensor):
             a = actions
             if a.dtype is not torch.float32 or a.device != self.device:
                 a = a.to(device=self.device, dtype=torch.float32)
         else:
-            a = torch.from_numpy(
-                np.ascontiguousarray(actions, dtype=np.float32)).to(self.device)
+            # a host array (the reference's contract, rl.py:93-94): through the
+            # pinned staging buffer, asynchronously.  The buffer is free again:
+            # step() has waited for the dones of the step that used it.
+            actions = np.asarray(actions)
+            n = self._n_active
+            if actions.shape != (n, 3):
+                raise ValueError(
+                    f'actions must be ({n}, 3), got {tuple(actions.shape)}')
+            io = self._host_io()
+            np.copyto(io['act_np'][:n], actions, casting='unsafe')
+            a = io['act_dev'][:n]
+            a.copy_(io['act_pin'][:n], non_blocking=True)
         a = a.contiguous()
         if a.shape != (self._n_active, 3):
             raise ValueError(
@@ -225,7 +256,12 @@ class TrackingEnvironment(BaseEnv):
         Only NoisyTrackingEnvironment returns something."""
         return None
 
-    def _launch_step(self, actions, order):
+    def _launch_step(self, actions, order, host_outputs=False):
+        """``host_outputs``: the caller wants ``dones`` (and ``reward``) on the
+        host (``step()``): they are final after the step's first kernel, so
+        their copies into pinned memory are queued right behind it, in front of
+        the index compaction and the state gather, and an event marks them --
+        ``step()`` returns while the gather is still running."""
         if self._pending is not None:
             raise RuntimeError('harvest() the previous step first')
         n = self._n_active
@@ -243,7 +279,20 @@ class TrackingEnvironment(BaseEnv):
             reward = torch.empty(n, dtype=torch.float64, device=self.device)
         noise_ptr = noise.data_ptr() if noise is not None else None
         reward_ptr = reward.data_ptr() if reward is not None else None
-        if not self._use_oracle_stopping:
+        early = host_outputs and not self._use_oracle_stopping and not self._use_oracle_reward
+        if early:
+            io = self._host_io()
+            _lib.check(self._lib.ttl_env_step_begin(
+                self._handle, a.data_ptr(), noise_ptr, n, reward_ptr,
+                done.data_ptr(), self._stream()), 'ttl_env_step_begin')
+            io['done_pin'][:n].copy_(done, non_blocking=True)
+            if reward is not None:
+                io['reward_pin'][:n].copy_(reward, non_blocking=True)
+            io['event'].record()
+            _lib.check(self._lib.ttl_env_step_end(
+                self._handle, None, order, state.data_ptr(), self._state_pitch,
+                self._host_counts.data_ptr(), self._stream()), 'ttl_env_step_end')
+        elif not self._use_oracle_stopping:
             _lib.check(self._lib.ttl_env_step(
                 self._handle, a.data_ptr(), noise_ptr, n, order,
                 state.data_ptr(), self._state_pitch, reward_ptr,
@@ -269,7 +318,7 @@ class TrackingEnvironment(BaseEnv):
                 n, self.length + 1, done, reward)
         self.length += 1
         self._pending = dict(order=order, state=state, n=n, done=done,
-                             keep=(a, noise))
+                             keep=(a, noise), early=early)
         return state, reward, done
 
     # -- oracle criterion / reward: torch ops between the library calls ----- #
@@ -321,12 +370,22 @@ class TrackingEnvironment(BaseEnv):
         N_total when rewards are off, tracking_env.py:204); ``dones`` bool
         numpy; ``info`` = {'continue_idx', 'reward_info'}.
         """
-        state, reward, done = self._launch_step(actions, _lib.ORDER_ACTIVE)
-        dones = done.to('cpu').numpy().astype(bool)      # syncs the stream
+        state, reward, done = self._launch_step(actions, _lib.ORDER_ACTIVE,
+                                                host_outputs=True)
+        n = self._pending['n']
+        if self._pending['early']:
+            # dones / reward were copied to pinned memory right behind the
+            # step's first kernel: wait for those copies only
+            io = self._io
+            io['event'].synchronize()
+            dones = io['done_np'][:n].astype(bool)
+            reward_np = io['reward_np'][:n].copy() if reward is not None else None
+        else:
+            dones = done.to('cpu').numpy().astype(bool)      # syncs the stream
+            reward_np = reward.to('cpu').numpy() if reward is not None else None
         self._pending['dones_host'] = dones
         reward_info = {}
         if reward is not None:
-            reward_np = reward.to('cpu').numpy()
             # reward.py:73-75: mean of each weighted factor
             oracle_np = np.zeros_like(reward_np)
             if self._last_oracle_term is not None:
@@ -334,9 +393,19 @@ class TrackingEnvironment(BaseEnv):
             reward_info = {'peaks_reward': np.mean(reward_np - oracle_np),
                            'oracle_reward': np.mean(oracle_np)}
         else:
-            reward_np = np.zeros(self._n_total)
+            # tracking_env.py:204: np.zeros(N_total) -- the same zeros every
+            # step, so one array per batch size (never written by the callers,
+            # which sum it: rl.py:97, ddpg.py:209)
+            reward_np = self._zero_reward(self._n_total)
         info = _StepInfo(self, self._pending['n'], reward_info)
         return state, reward_np, dones, info
+
+    def _zero_reward(self, n):
+        z = getattr(self, '_zero_reward_np', None)
+        if z is None or z.shape[0] != n:
+            z = self._zero_reward_np = np.zeros(n)
+            z.flags.writeable = False       # shared between steps: writing it raises
+        return z
 
     def step_device(self, actions):
         """Device-resident step: no host copy, no sync.  ``state`` rows are
