@@ -227,11 +227,19 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
             rows.append(state.cpu().numpy())
         return env, rows
 
+    monkeypatch.setenv('TTL_PLACEMENT_EARLY_EXIT', '0')    # time every pair on any box
     env_t, rows_t = run(3)
     assert len(env_t._sh_tuned) == 3
     assert all(len(r) == env_t.STATE_RING_CANDIDATES + 1 and min(r) > 0.0
                for r in env_t._sh_tuned)               # 16 rings + the allocator's blocks
     assert env_t._sh_packed.data_ptr() == env_t._sh_memory.ptr
+    # the search is bounded: what it held on top of the env's own buffers stayed
+    # within its budget (8 GiB and a tenth of the free device memory)
+    search = env_t._placement_search
+    assert search['pairs_timed'] == 51 and not search['early_exit']
+    assert search['bytes_held'] <= search['budget_bytes'] <= 8 << 30
+    assert search['budget_bytes'] <= 0.1 * search['free_bytes_at_start'] + 1
+    assert env_t.state_ring_len in (0, env_t.STATE_RING)
     env_1, rows_1 = run(1)
     assert env_1._sh_tuned == []
     for a, b in zip(rows_t, rows_1):
@@ -267,3 +275,60 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
     # a second large reset does not tune again
     env_t.reset(0, N)
     assert len(env_t._sh_tuned) == 3
+
+
+def test_placement_search_stops_early_and_respects_a_small_budget(monkeypatch):
+    """Round 3: (i) when the first three pairs agree within 2 % the search stops
+    (forced here with a 100 % band), keeps the first volume and a ring of the
+    first buffers; (ii) a budget too small for a ring of state buffers leaves
+    the allocator's blocks in place; either way the steps are unchanged."""
+    N = 65536
+
+    def first_rows(env):
+        state = env.reset(0, N)
+        rows = [state.cpu().numpy()]
+        for step in range(2):
+            env.step_device(env.scripted_actions(state, step, seed=3, wobble=0.05))
+            state, _ = env.harvest()
+            rows.append(state.cpu().numpy())
+        return rows
+
+    from tracktolearn_amd.environments.env import BaseEnv
+    monkeypatch.setattr(BaseEnv, 'PLACEMENT_EARLY_EXIT', 1.0)
+    env_a, _ = _make(96, N, 4, noisy=False, reward=False, max_length=60.0)
+    rows_a = first_rows(env_a)
+    assert env_a._placement_search['early_exit'] and env_a._placement_search['pairs_timed'] == 3
+    assert len(env_a._sh_tuned) == 1 and len(env_a._sh_tuned[0]) == 3
+    assert env_a.state_ring_len == env_a.STATE_RING
+    monkeypatch.setattr(BaseEnv, 'PLACEMENT_EARLY_EXIT', 0.02)
+    monkeypatch.setenv('TTL_PLACEMENT_SEARCH_BYTES', str(200 << 20))   # < one volume copy + a ring
+    env_b, _ = _make(96, N, 4, noisy=False, reward=False, max_length=60.0)
+    rows_b = first_rows(env_b)
+    assert env_b._placement_search['state_buffer_candidates'] == 0
+    assert env_b._placement_search['volume_candidates'] == 1
+    assert env_b.state_ring_len == 0 and env_b._sh_tuned == []
+    for a, b in zip(rows_a, rows_b):
+        assert np.array_equal(a, b)
+
+
+def test_a_refused_allocation_leaves_the_runtime_clean():
+    """`ttl_volume_alloc` is how the placement search probes for room.
+    A refused allocation must not leave its error behind: the next launch check
+    -- the library's or torch's -- would report it as its own."""
+    import ctypes as C
+    from tracktolearn_amd import _lib
+    lib = _lib.load()
+    ptr, flag = C.c_void_p(), C.c_int32()
+    rc = lib.ttl_volume_alloc(0, 1 << 46, 0, C.byref(ptr), C.byref(flag))      # 64 TiB
+    assert rc == _lib.ERR_HIP and b'ttl_volume_alloc' in lib.ttl_last_error()
+    with pytest.raises(_lib.TTLError):
+        _lib.DeviceVolume(0, 1 << 46)
+    # torch's own launch check and the library's next calls see no stale error
+    x = torch.ones(1024, device='cuda:0')
+    assert float((x * 2).sum()) == 2048.0
+    env, _ = _make(24, 4096, 4, noisy=False, reward=False, max_length=30.0)
+    state = env.reset(0, 4096)
+    env.step_device(env.scripted_actions(state, 0, seed=3, wobble=0.05))
+    state, _ = env.harvest()
+    torch.cuda.synchronize()
+    assert state.shape[0] > 0

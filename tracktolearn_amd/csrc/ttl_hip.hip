@@ -237,7 +237,8 @@ __device__ __forceinline__ void block_ranks(int *__restrict__ rank_out,
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w)
         if (w < wave) before += wave_total[w];
-    if (active) rank_out[i] = before + below;
+    // rank in the low bits, "stopped" in the sign bit (see block_survivor_ranks_scan)
+    if (active) rank_out[i] = (before + below) | (keep ? 0 : (int)0x80000000);
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
@@ -255,17 +256,25 @@ __device__ __forceinline__ void block_survivor_ranks(const EnvParams &P, int i,
 // The exclusive prefix over the per-workgroup survivor counts, computed by the
 // LAST workgroup of the same launch to arrive (round 3; it used to be a launch
 // of its own in which every workgroup summed its predecessors' counts).
-// Every workgroup publishes its count (agent-scope atomic store, drained, then
-// an agent-scope release) and takes a ticket; the one whose ticket is the last
-// reads all counts back (agent-scope atomic loads behind an acquire), scans
-// them, and writes P.block_before[], the totals and -- straight into the
-// caller's pinned buffer, sequence number last -- the survivor count the host
-// is polling for.  Nobody waits for anybody: no spin, no residency assumption.
-// The ticket word is left at zero for the next launch.
-// Same ranks and counts as block_survivor_ranks().
+// Every workgroup publishes its count as ONE 8-byte granule {epoch, count}
+// (agent-scope atomic store = write-through; the data is its own flag,
+// cdna_hip_programming.md G16 form R2), drains it, and takes a ticket
+// (agent-scope atomic add).  The workgroup whose ticket is the last re-reads the
+// granules (agent-scope atomic loads: they do not stop at this CU's L1 or at a
+// stale L2 line) until each carries this launch's epoch -- they all do at the
+// first pass, the stores were drained before the tickets -- scans them, and
+// writes P.block_before[], the totals and, straight into the caller's pinned
+// buffer, sequence number last, the survivor count the host is polling for.
+// No release / acquire FENCE anywhere: an agent-scope release writes back the
+// XCD's whole L2 (measured: k_advance 0.023 -> 0.053 ms with one per
+// workgroup), and nothing but the granules crosses workgroups inside the
+// launch.  Nobody waits for another workgroup's progress: no residency
+// assumption.  The re-read is bounded; a granule that never shows up reports
+// -1 survivors, which the host turns into an error.  The ticket word is left
+// at zero for the next launch.  Same ranks and counts as block_ranks().
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void block_survivor_ranks_scan(
-    const EnvParams &P, int i, bool active, bool keep, int n_active,
+    const EnvParams &P, int i, bool active, bool keep, int n_active, unsigned epoch,
     int *__restrict__ host_word, int seq) {
     const unsigned long long m = __ballot(keep);
     const int lane = threadIdx.x & 63;
@@ -274,37 +283,49 @@ __device__ __forceinline__ void block_survivor_ranks_scan(
     __shared__ int wave_total[BLOCK / 64];
     __shared__ int s_last;
     __shared__ int s_run;
+    __shared__ int s_bad;
     if (lane == 0) wave_total[wave] = __popcll(m);
     __syncthreads();
     int before = 0;
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w)
         if (w < wave) before += wave_total[w];
-    if (active) P.rank[i] = before + below;
+    // rank in the low bits, "stopped" in the sign bit: one word per row tells
+    // the step's tail everything it needs
+    if (active) P.rank[i] = (before + below) | (keep ? 0 : (int)0x80000000);
     const int n_blocks = gridDim.x;
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) tot += wave_total[w];
-        __hip_atomic_store(P.block_counts + blockIdx.x, tot, __ATOMIC_RELAXED,
+        __hip_atomic_store(P.block_tagged + blockIdx.x,
+                           ((unsigned long long)epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the granule has left this CU
         const int ticket = __hip_atomic_fetch_add(P.counts + TTL_SCAN_TICKET, 1, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
         s_last = ticket == n_blocks - 1;
         s_run = 0;
+        s_bad = 0;
     }
     __syncthreads();
     if (!s_last) return;
     // ---- the last workgroup to arrive: scan the counts of all of them ----
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int base = 0; base < n_blocks; base += BLOCK) {
         const int b = base + (int)threadIdx.x;
-        const int c = b < n_blocks ? __hip_atomic_load(P.block_counts + b, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT)
-                                   : 0;
+        int c = 0;
+        if (b < n_blocks) {
+            unsigned long long g = 0;
+            bool ok = false;
+            for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
+                g = __hip_atomic_load(P.block_tagged + b, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(g >> 32) == epoch;
+                if (!ok) __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) s_bad = 1;
+            c = (int)(unsigned)g;
+        }
         int v = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -324,7 +345,7 @@ __device__ __forceinline__ void block_survivor_ranks_scan(
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int total = s_run;
+        const int total = s_bad ? -1 : s_run;
         P.block_before[n_blocks] = total;
         P.counts[0] = total;
         P.counts[1] = n_active - total;
@@ -502,11 +523,12 @@ __global__ __launch_bounds__(BLOCK) void k_advance(
     bool stop = false;
     if (active)
         stop = advance_row<MODE>(P, idx[i], i, actions, noise, L, reward_out, done_out);
-    // scan (wave-uniform): the large-batch step tail follows (k_rows / k_slots
-    // need the prefix over the workgroups); otherwise the one-launch tail scans
-    // the <= 64 counts itself
+    // scan (uniform; != 0: this launch's epoch): the large-batch step tail
+    // follows (k_tail needs the prefix over the workgroups); otherwise the
+    // one-launch tail scans the <= 64 counts itself
     if (scan)
-        block_survivor_ranks_scan(P, i, active, active && !stop, n_active, host_word, seq);
+        block_survivor_ranks_scan(P, i, active, active && !stop, n_active, (unsigned)scan,
+                                  host_word, seq);
     else
         block_survivor_ranks(P, i, active, active && !stop);
 }
@@ -590,59 +612,43 @@ __global__ __launch_bounds__(BLOCK) void k_restop(EnvParams P,
         }
     }
     if (scan)
-        block_survivor_ranks_scan(P, i, active, active && !stop, n_active, host_word, seq);
+        block_survivor_ranks_scan(P, i, active, active && !stop, n_active, (unsigned)scan,
+                                  host_word, seq);
     else
         block_survivor_ranks(P, i, active, active && !stop);
 }
 
 // ---------------------------------------------------------------------------
-// Step tail of large batches, after k_advance (whose last workgroup left the
-// exclusive prefix over the workgroups in P.block_before and the totals in
-// P.counts): the stable scatter of continue_idx (tracking_env.py:192-195) and
-// the active-row -> state-row map.  One of two kernels:
-//   k_rows   no processing order: one thread per active row;
-//   k_slots  with a processing order: one thread per slot, one workgroup per
-//            segment of the order, which it also compacts and re-sorts.
+// k_tail: the step tail of large batches, ONE launch after k_advance (whose
+// last workgroup left the exclusive prefix over the workgroups in
+// P.block_before and the totals in P.counts).  Two kinds of workgroup in one
+// grid, independent of each other (both read only what k_advance wrote):
+//   workgroups [0, n_row_blocks): one thread per active ROW, coalesced -- the
+//     stable scatter of continue_idx (tracking_env.py:192-195), the
+//     active-row -> state-row map, the lengths of the streamlines that stopped;
+//   workgroups [n_row_blocks, + segments): one thread per SLOT of the
+//     processing order, one workgroup per segment -- this step's per-slot
+//     records for the gather, the segment compacted and re-sorted for the next
+//     step.  None when the batch has no processing order.
+// Rounds 1-2 spent three launches on this (k_prefix: every workgroup summing
+// its predecessors' counts, k_proc_scatter: the same over the slot counts).
 // ---------------------------------------------------------------------------
-// what the step decided for active row `row` (g = idx[row]); writes the
-// per-row outputs, returns the position among the survivors (-1: stopped) and
-// the state row
-__device__ __forceinline__ int2 resolve_row(const EnvParams &P, int row, int g,
-                                            int *__restrict__ idx_next, int total, int order,
-                                            int n_pts) {
-    const int pos = P.block_before[row >> 8] + P.rank[row];
-    const bool stop = P.stop[row] != 0;
-    if (!stop) idx_next[pos] = g;
-    // ORDER_PARTITION has no separate harvest kernel: record the final length
-    // of the streamlines that just stopped here (tracking_env.py:236)
-    if (stop && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
-    P.surv_pos[row] = stop ? -1 : pos;
+struct RowFate {
+    int pos;    // position among the survivors, -1: stopped in this step
+    int dest;   // state row written for it
+};
+// what the step decided for active row `row`, from the one word k_advance left
+__device__ __forceinline__ RowFate row_fate(const EnvParams &P, int row, int total, int order) {
+    const int rs = P.rank[row];
+    const bool stop = rs < 0;
+    const int pos = P.block_before[row >> 8] + (rs & 0x7fffffff);
     int dest = row;
     if (order == TTL_ORDER_PARTITION) dest = stop ? total + (row - pos) : pos;
-    P.row_dest[row] = dest;
-    return int2{stop ? -1 : pos, dest};
+    return RowFate{stop ? -1 : pos, dest};
 }
 
-static_assert(BLOCK == 256, "resolve_row: rows per k_advance workgroup = 1 << 8");
+static_assert(BLOCK == 256, "row_fate: rows per k_advance workgroup = 1 << 8");
 
-__global__ __launch_bounds__(BLOCK) void k_rows(EnvParams P, const int *__restrict__ idx,
-                                                int *__restrict__ idx_next, int n_active,
-                                                int order, int n_pts) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_active) return;
-    resolve_row(P, i, idx[i], idx_next, P.counts[0], order, n_pts);
-}
-
-// ---------------------------------------------------------------------------
-// Processing order of the state gather.  Row order (continue_idx order) is
-// fixed by the reference, but WHICH rows a workgroup gathers is free: proc
-// lists the active rows sorted by the 8^3-voxel brick of their seed, so that a
-// workgroup -- and its neighbours in time on the same XCD -- fetch voxels that
-// are already in L2 instead of going to the Infinity Cache / HBM for each
-// streamline separately.  The order is kept in segments (ttl_internal.h); each
-// step every segment is compacted (stable, in its own order) and renumbered
-// with the survivors' new row ids.
-// ---------------------------------------------------------------------------
 // low 6 bits of v spread to every third bit (Morton interleave helper)
 __device__ __forceinline__ unsigned spread3(unsigned v) {
     v &= 63u;
@@ -652,31 +658,57 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {
     return v;
 }
 
-// one workgroup per segment: slot t of segment s (t < seg_in[s]) holds active
-// row proc[s * SEG + t]
-__global__ __launch_bounds__(BLOCK) void k_slots(EnvParams P, const int *__restrict__ proc,
-                                                 int *__restrict__ proc_next,
-                                                 const int *__restrict__ seg_in,
-                                                 int *__restrict__ seg_out,
-                                                 int *__restrict__ idx_next, int order,
-                                                 int n_pts, int local_sort) {
+// Processing order of the state gather.  Row order (continue_idx order) is
+// fixed by the reference, but WHICH rows a workgroup gathers is free: proc
+// lists the active rows sorted by the 8^3-voxel brick of their seed, so that a
+// workgroup -- and its neighbours in time on the same XCD -- fetch voxels that
+// are already in L2 instead of going to the Infinity Cache / HBM for each
+// streamline separately.  The order is kept in segments (ttl_internal.h); each
+// step every segment is compacted (stable, in its own order) and renumbered
+// with the survivors' new row ids.
+__global__ __launch_bounds__(BLOCK) void k_tail(EnvParams P, const int *__restrict__ idx,
+                                                int *__restrict__ idx_next, int n_active,
+                                                int n_row_blocks, int order, int n_pts,
+                                                const int *__restrict__ proc,
+                                                int *__restrict__ proc_next,
+                                                const int *__restrict__ seg_in,
+                                                int *__restrict__ seg_out, int local_sort) {
+    const int total = P.counts[0];
+    if ((int)blockIdx.x < n_row_blocks) {
+        // ---- rows: coalesced per-row outputs ----
+        const int i = blockIdx.x * BLOCK + threadIdx.x;
+        if (i >= n_active) return;
+        const RowFate f = row_fate(P, i, total, order);
+        const int g = idx[i];
+        if (f.pos >= 0) idx_next[f.pos] = g;
+        // ORDER_PARTITION has no separate harvest kernel: record the final
+        // length of the streamlines that just stopped here (tracking_env.py:236)
+        if (f.pos < 0 && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
+        P.surv_pos[i] = f.pos;
+        P.row_dest[i] = f.dest;
+        return;
+    }
+    // ---- slots: one workgroup per segment; slot t of segment s (t < seg_in[s])
+    // holds active row proc[s * SEG + t] ----
     __shared__ int red[BLOCK / 64];
     __shared__ unsigned s_key[BLOCK];
     __shared__ int s_pos[BLOCK];
+    const int seg = blockIdx.x - n_row_blocks;
     const int SEG = P.seg_slots;
-    const size_t base = (size_t)blockIdx.x * SEG;
-    const int cnt = seg_in[blockIdx.x];
+    const size_t base = (size_t)seg * SEG;
+    const int cnt = seg_in[seg];
     const bool active = (int)threadIdx.x < cnt;
     float4 hd = float4{0.f, 0.f, 0.f, 0.f};
-    int2 pd = int2{-1, 0};
+    RowFate f{-1, 0};
     if (active) {
         const int row = proc[base + threadIdx.x];
-        // the head record carries idx[row] in .w: everything this step's state
+        // two scattered loads per slot: the head record (its .w carries
+        // idx[row]) and the row's rank word.  Everything this step's state
         // gather needs to know about the slot is resolved here, one thread per
         // slot, so that the gather (12 lanes per slot) starts from two
         // coalesced loads
         hd = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
-        pd = resolve_row(P, row, __float_as_int(hd.w), idx_next, P.counts[0], order, n_pts);
+        f = row_fate(P, row, total, order);
     }
     // Local re-sort: the slots of this segment are put in Morton order of the
     // voxel their streamline sits in now.  The global order (8^3 bricks,
@@ -710,9 +742,9 @@ __global__ __launch_bounds__(BLOCK) void k_slots(EnvParams P, const int *__restr
     if (active) {
         const size_t o = base + rank;
         *reinterpret_cast<float4 *>(P.slot_head + 4 * o) = hd;
-        P.slot_dest[o] = pd.y;
+        P.slot_dest[o] = f.dest;
     }
-    s_pos[rank] = active ? pd.x : -1;            // surv_pos (or -1) in sorted order
+    s_pos[rank] = active ? f.pos : -1;           // surv_pos (or -1) in sorted order
     __syncthreads();
     // next step's segment: the survivors, in this sorted order
     const int pos = s_pos[threadIdx.x];
@@ -729,7 +761,7 @@ __global__ __launch_bounds__(BLOCK) void k_slots(EnvParams P, const int *__restr
         kept += red[w];
     }
     if (keep) proc_next[base + wave_before + below] = pos;
-    if (threadIdx.x == 0) seg_out[blockIdx.x] = kept;
+    if (threadIdx.x == 0) seg_out[seg] = kept;
 }
 
 // a dense order of n rows as segments: every segment full but the last
@@ -1040,6 +1072,7 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     b += align_up(n * 8 * sizeof(float), 256); // last2
     b += align_up(ns * sizeof(int), 256);     // slot_dest
     b += 2 * align_up((nb + 1) * sizeof(int), 256); // block_counts, block_before
+    b += align_up((nb + 1) * sizeof(unsigned long long), 256); // block_tagged
     b += 2 * align_up((n / 240 + 2) * sizeof(int), 256); // seg_cnt x2 (segments are >= 240 slots)
     b += 256;                                 // counts
     b += ttl_detail_order_workspace_bytes(n); // order refresh scratch
@@ -1281,6 +1314,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     const size_t ns = n + BLOCK;
     P.block_counts = (int *)w;    w += align_up((nb + 1) * sizeof(int), 256);
     P.block_before = (int *)w;    w += align_up((nb + 1) * sizeof(int), 256);
+    P.block_tagged = (unsigned long long *)w;  w += align_up((nb + 1) * sizeof(unsigned long long), 256);
     e->proc[0] = (int *)w;        w += align_up(ns * sizeof(int), 256);
     e->proc[1] = (int *)w;        w += align_up(ns * sizeof(int), 256);
     e->seg_cnt[0] = (int *)w;     w += align_up((n / 240 + 2) * sizeof(int), 256);
@@ -1515,6 +1549,14 @@ static int *host_word_for(ttl_env *env, int32_t *host_counts, int *seq_out) {
     return env->host_dev;
 }
 
+// epoch of a scanning launch (k_advance / k_restop): nonzero, fresh per launch
+static int next_epoch() {
+    static std::atomic<unsigned> g_epoch{1};
+    unsigned e = g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x7fffffffu;
+    if (e == 0) e = g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x7fffffffu;
+    return (int)e;
+}
+
 static void expect_polled_counts(ttl_env *env, int32_t *host_counts, int seq, hipStream_t s) {
     env->counts_pending = 2;
     env->host_counts = host_counts;
@@ -1553,7 +1595,8 @@ static int step_begin(ttl_env *env, const float *actions, const double *noise,
     env->tail_small = !env->use_proc && can_fuse && env->state_kernel != 0;
     // large batches: the last workgroup of k_advance scans the per-workgroup
     // counts and hands the survivor count to the host
-    const int scan = !env->tail_small;
+    // (a fresh nonzero epoch per scanning launch tags the count granules)
+    const int scan = env->tail_small ? 0 : next_epoch();
     int seq = 0;
     int *host_word = scan ? host_word_for(env, host_counts, &seq) : nullptr;
     env->pend_host_word = host_word;
@@ -1612,7 +1655,7 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         // external stop bits (the oracle criterion): redo the ranks -- and, for
         // the large-batch tail, the scan and the count the host polls for
         hipLaunchKernelGGL(k_restop, dim3(nb), dim3(BLOCK), 0, s, env->P, idx,
-                           extra_flags, n_active, env->last_done, small ? 0 : 1,
+                           extra_flags, n_active, env->last_done, small ? 0 : next_epoch(),
                            small ? nullptr : host_word, seq);
         HIP_TRY(hipGetLastError());
     } else if (!small && !published && host_word) {
@@ -1641,17 +1684,15 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         HIP_TRY(ttl_copy_counts(env, host_counts, s));
     }
     prof_mark(env, 1, 0, s);
-    if (proc) {
-        // one workgroup per segment of the processing order: this step's
-        // per-slot records for the gather, the index compaction, and the next
-        // step's segment (survivors, renumbered with their new row ids)
+    {
+        // one launch: a workgroup per 256 rows (index compaction, row map) and,
+        // with a processing order, a workgroup per segment of it (per-slot
+        // records for the gather, the next step's segment)
         const int which = env->proc_cur;
-        hipLaunchKernelGGL(k_slots, dim3(env->proc_nseg), dim3(BLOCK), 0, s, env->P, proc,
-                           env->proc[which ^ 1], env->seg_cnt[which], env->seg_cnt[which ^ 1],
-                           idx_next, order, n_pts, env->local_sort);
-    } else {
-        hipLaunchKernelGGL(k_rows, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
-                           n_active, order, n_pts);
+        const int nseg = proc ? env->proc_nseg : 0;
+        hipLaunchKernelGGL(k_tail, dim3(nb + nseg), dim3(BLOCK), 0, s, env->P, idx, idx_next,
+                           n_active, nb, order, n_pts, proc, env->proc[which ^ 1],
+                           env->seg_cnt[which], env->seg_cnt[which ^ 1], env->local_sort);
     }
     prof_mark(env, 1, 1, s);
     HIP_TRY(hipGetLastError());
@@ -1749,6 +1790,9 @@ int ttl_env_wait_counts(ttl_env *env) {
     env->counts_pending = 0;
     // the handle now knows the exact number of survivors: the next step must
     // be launched for exactly that many rows
+    if (env->host_counts && env->host_counts[0] < 0)
+        return fail(TTL_ERR_HIP, "ttl_env_wait_counts: the step's survivor scan never saw "
+                                 "every workgroup's count (GPU memory fault?)");
     if (env->host_counts && !env->stepped) {
         env->n_active = env->host_counts[0];
         env->n_exact = 1;

@@ -55,11 +55,12 @@ struct EnvParams {
     uint8_t *stop;     // [n_max] 1 = stopped in the last step
     float *head;       // [n_max][4] newest point of every active row (row order), .w = bits of idx[row]
     float *last2;      // [n_max][8] per streamline id: {p[L-2], pad, p[L-1], pad}, the two newest points
-    int *rank;         // [n_max] survivors before this row inside its block
+    int *rank;         // [n_max] survivors before this row inside its block; sign bit: the row stopped
     int *surv_pos;     // [n_max] position among survivors, -1 if stopped
     int *row_dest;     // [n_max] state row written for this active row
     int *block_counts; // [ceil(n_max/BLOCK)] survivors per block of k_advance
     int *block_before; // [ceil(n_max/BLOCK) + 1] survivors in the blocks before this one (k_advance's last block)
+    unsigned long long *block_tagged; // [ceil(n_max/BLOCK)] {epoch, count} granules of a scanning launch
     float *slot_head;  // [n_max + 256][4] per slot of the processing order: newest point, .w = bits of idx[row]
     int *slot_dest;    // [n_max + 256] per slot of the processing order: row_dest[row]
     int seg_slots;     // slots per segment of the processing order (see TTL_SEG_* below)

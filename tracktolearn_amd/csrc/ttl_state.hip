@@ -555,7 +555,7 @@ __device__ __forceinline__ void prefix_state_body(
     const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
     const int g = __float_as_int(hp.w);
     const bool stop = P.stop[row] != 0;
-    const int pos = s_before[row >> 8] + P.rank[row];
+    const int pos = s_before[row >> 8] + (P.rank[row] & 0x7fffffff);
     int dest = row;
     if (order == TTL_ORDER_PARTITION) dest = stop ? total + (row - pos) : pos;
     if (sub == 0) {

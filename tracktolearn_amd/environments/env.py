@@ -484,6 +484,17 @@ class BaseEnv(object):
     #: a fresh ``torch.empty`` per step, as ``step()`` always does)
     STATE_RING = 4
 
+    @property
+    def state_ring_len(self):
+        """How many state tensors of the device-resident loop are alive at a time:
+        a tensor returned by ``reset`` / ``step_device`` / ``harvest`` stays intact
+        while at most ``state_ring_len - 1`` further state tensors are handed out,
+        then its buffer is reused.  0: every tensor is a fresh allocation (small
+        batches, ``TTL_STATE_RING=0``, and always ``step()``).  Callers that keep
+        states across steps (n-step buffers, trajectories) clone, or assert on
+        this."""
+        return len(self._state_ring) if getattr(self, '_state_ring', None) else 0
+
     def _ring_state(self, n):
         """State rows for a reset / ``step_device``: the next buffer of the placed
         ring when there is one that fits, a fresh tensor otherwise."""
