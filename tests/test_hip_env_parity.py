@@ -77,13 +77,21 @@ def _close(a, b, tol=TOL):
 FUSED = pytest.mark.parametrize('fused', ['1', '0'])
 
 
+#: step() hands its state rows out as a lazily gathered tensor over rows written
+#: survivors first (harvest() is then a view); False: rows written in the
+#: reference's order, harvest() copies the survivors' rows (k_finish, k_copy_rows)
+LAZY = pytest.mark.parametrize('lazy', [True, False])
+
+
+@LAZY
 @FUSED
 @pytest.mark.parametrize('name', TRACES)
-def test_reference_trace_step_harvest(name, fused, monkeypatch):
+def test_reference_trace_step_harvest(name, fused, lazy, monkeypatch):
     """step()/harvest() -- the reference's calling contract."""
     monkeypatch.setenv('TTL_FUSE_SMALL', fused)
     z = load_trace(name)
     env = _env_from_trace(z)
+    env.lazy_step_state = lazy
     N = z['seeds'].shape[0]
     state = env.reset(0, N)
     assert state.dtype == torch.float32 and state.is_cuda
@@ -91,6 +99,8 @@ def test_reference_trace_step_harvest(name, fused, monkeypatch):
     for s in range(int(z['n_steps'])):
         assert np.array_equal(env.continue_idx, z[f'continue_idx_{s}'])
         nstate, rew, done, info = env.step(z[f'actions_{s}'].copy())
+        assert isinstance(nstate, torch.Tensor) and nstate.is_cuda
+        assert nstate.dtype == torch.float32 and nstate.shape[0] == len(z[f'dones_{s}'])
         assert done.dtype == bool and np.array_equal(done, z[f'dones_{s}'])
         assert np.array_equal(info['continue_idx'], z[f'continue_idx_{s}'])
         assert np.array_equal(env.flags, z[f'flags_{s}'])

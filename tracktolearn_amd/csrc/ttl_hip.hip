@@ -12,8 +12,7 @@
 //                (LENGTH / CURVATURE / MASK tests, flags, dones),
 //                reward.py:46-79 + local_reward.py:29-107 (alignment reward),
 //                and the wave-ballot survivor ranks for the compaction.
-//   k_advance's last workgroup + k_rows / k_slots :
-//                tracking_env.py:192-195 / 238-241 (stable index compaction:
+//   k_prefix   : tracking_env.py:192-195 / 238-241 (stable index compaction:
 //                new_continue_idx = continue_idx[~stopping]).
 //   k_state*   : env.py:504-565 (_format_state): 7-point trilinear gather of
 //                the SH volume + last K segment vectors -> ttl_state.hip.
@@ -237,8 +236,7 @@ __device__ __forceinline__ void block_ranks(int *__restrict__ rank_out,
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w)
         if (w < wave) before += wave_total[w];
-    // rank in the low bits, "stopped" in the sign bit (see block_survivor_ranks_scan)
-    if (active) rank_out[i] = (before + below) | (keep ? 0 : (int)0x80000000);
+    if (active) rank_out[i] = before + below;
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
@@ -250,117 +248,6 @@ __device__ __forceinline__ void block_ranks(int *__restrict__ rank_out,
 __device__ __forceinline__ void block_survivor_ranks(const EnvParams &P, int i,
                                                      bool active, bool keep) {
     block_ranks(P.rank, P.block_counts, i, active, keep);
-}
-
-// ---------------------------------------------------------------------------
-// The exclusive prefix over the per-workgroup survivor counts, computed by the
-// LAST workgroup of the same launch to arrive (round 3; it used to be a launch
-// of its own in which every workgroup summed its predecessors' counts).
-// Every workgroup publishes its count as ONE 8-byte granule {epoch, count}
-// (agent-scope atomic store = write-through; the data is its own flag,
-// cdna_hip_programming.md G16 form R2), drains it, and takes a ticket
-// (agent-scope atomic add).  The workgroup whose ticket is the last re-reads the
-// granules (agent-scope atomic loads: they do not stop at this CU's L1 or at a
-// stale L2 line) until each carries this launch's epoch -- they all do at the
-// first pass, the stores were drained before the tickets -- scans them, and
-// writes P.block_before[], the totals and, straight into the caller's pinned
-// buffer, sequence number last, the survivor count the host is polling for.
-// No release / acquire FENCE anywhere: an agent-scope release writes back the
-// XCD's whole L2 (measured: k_advance 0.023 -> 0.053 ms with one per
-// workgroup), and nothing but the granules crosses workgroups inside the
-// launch.  Nobody waits for another workgroup's progress: no residency
-// assumption.  The re-read is bounded; a granule that never shows up reports
-// -1 survivors, which the host turns into an error.  The ticket word is left
-// at zero for the next launch.  Same ranks and counts as block_ranks().
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void block_survivor_ranks_scan(
-    const EnvParams &P, int i, bool active, bool keep, int n_active, unsigned epoch,
-    int *__restrict__ host_word, int seq) {
-    const unsigned long long m = __ballot(keep);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int below = __popcll(m & ((1ull << lane) - 1ull));
-    __shared__ int wave_total[BLOCK / 64];
-    __shared__ int s_last;
-    __shared__ int s_run;
-    __shared__ int s_bad;
-    if (lane == 0) wave_total[wave] = __popcll(m);
-    __syncthreads();
-    int before = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w)
-        if (w < wave) before += wave_total[w];
-    // rank in the low bits, "stopped" in the sign bit: one word per row tells
-    // the step's tail everything it needs
-    if (active) P.rank[i] = (before + below) | (keep ? 0 : (int)0x80000000);
-    const int n_blocks = gridDim.x;
-    if (threadIdx.x == 0) {
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w) tot += wave_total[w];
-        __hip_atomic_store(P.block_tagged + blockIdx.x,
-                           ((unsigned long long)epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the granule has left this CU
-        const int ticket = __hip_atomic_fetch_add(P.counts + TTL_SCAN_TICKET, 1, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == n_blocks - 1;
-        s_run = 0;
-        s_bad = 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // ---- the last workgroup to arrive: scan the counts of all of them ----
-    for (int base = 0; base < n_blocks; base += BLOCK) {
-        const int b = base + (int)threadIdx.x;
-        int c = 0;
-        if (b < n_blocks) {
-            unsigned long long g = 0;
-            bool ok = false;
-            for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
-                g = __hip_atomic_load(P.block_tagged + b, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-                ok = (unsigned)(g >> 32) == epoch;
-                if (!ok) __builtin_amdgcn_s_sleep(2);
-            }
-            if (!ok) s_bad = 1;
-            c = (int)(unsigned)g;
-        }
-        int v = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(v, off);
-            if (lane >= off) v += t;
-        }
-        __syncthreads();                     // wave_total / s_run of the previous tile are read
-        if (lane == 63) wave_total[wave] = v;
-        __syncthreads();
-        int excl = s_run + v - c;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; ++w)
-            if (w < wave) excl += wave_total[w];
-        if (b < n_blocks) P.block_before[b] = excl;
-        __syncthreads();
-        if (threadIdx.x == BLOCK - 1) s_run = excl + c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int total = s_bad ? -1 : s_run;
-        P.block_before[n_blocks] = total;
-        P.counts[0] = total;
-        P.counts[1] = n_active - total;
-        __hip_atomic_store(P.counts + TTL_SCAN_TICKET, 0, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        if (host_word) {
-            // straight into the caller's pinned buffer, sequence number last:
-            // the host polls it (ttl_env_wait_counts) and can queue the next
-            // step while this step's other kernels are still running
-            __hip_atomic_store(host_word + 0, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(host_word + 1, n_active - total, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(host_word + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -516,21 +403,13 @@ template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_advance(
     EnvParams P, const int *__restrict__ idx, const float *__restrict__ actions,
     const double *__restrict__ noise, int n_active, int L,
-    double *__restrict__ reward_out, uint8_t *__restrict__ done_out, int scan,
-    int *__restrict__ host_word, int seq) {
+    double *__restrict__ reward_out, uint8_t *__restrict__ done_out) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < n_active;
     bool stop = false;
     if (active)
         stop = advance_row<MODE>(P, idx[i], i, actions, noise, L, reward_out, done_out);
-    // scan (uniform; != 0: this launch's epoch): the large-batch step tail
-    // follows (k_tail needs the prefix over the workgroups); otherwise the
-    // one-launch tail scans the <= 64 counts itself
-    if (scan)
-        block_survivor_ranks_scan(P, i, active, active && !stop, n_active, (unsigned)scan,
-                                  host_word, seq);
-    else
-        block_survivor_ranks(P, i, active, active && !stop);
+    block_survivor_ranks(P, i, active, active && !stop);
 }
 
 // ---------------------------------------------------------------------------
@@ -594,14 +473,13 @@ __global__ __launch_bounds__(BLOCK) void k_restop(EnvParams P,
                                                   const int *__restrict__ idx,
                                                   const uint8_t *__restrict__ extra,
                                                   int n_active,
-                                                  uint8_t *__restrict__ done_out, int scan,
-                                                  int *__restrict__ host_word, int seq) {
+                                                  uint8_t *__restrict__ done_out) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < n_active;
     bool stop = false;
     if (active) {
         stop = P.stop[i] != 0;
-        const int bits = extra ? extra[i] : 0;
+        const int bits = extra[i];
         if (bits) {
             const int g = idx[i];
             P.flags[g] = (stop ? P.flags[g] : 0) | bits;
@@ -611,44 +489,92 @@ __global__ __launch_bounds__(BLOCK) void k_restop(EnvParams P,
             stop = true;
         }
     }
-    if (scan)
-        block_survivor_ranks_scan(P, i, active, active && !stop, n_active, (unsigned)scan,
-                                  host_word, seq);
-    else
-        block_survivor_ranks(P, i, active, active && !stop);
+    block_survivor_ranks(P, i, active, active && !stop);
 }
 
 // ---------------------------------------------------------------------------
-// k_tail: the step tail of large batches, ONE launch after k_advance (whose
-// last workgroup left the exclusive prefix over the workgroups in
-// P.block_before and the totals in P.counts).  Two kinds of workgroup in one
-// grid, independent of each other (both read only what k_advance wrote):
-//   workgroups [0, n_row_blocks): one thread per active ROW, coalesced -- the
-//     stable scatter of continue_idx (tracking_env.py:192-195), the
-//     active-row -> state-row map, the lengths of the streamlines that stopped;
-//   workgroups [n_row_blocks, + segments): one thread per SLOT of the
-//     processing order, one workgroup per segment -- this step's per-slot
-//     records for the gather, the segment compacted and re-sorted for the next
-//     step.  None when the batch has no processing order.
-// Rounds 1-2 spent three launches on this (k_prefix: every workgroup summing
-// its predecessors' counts, k_proc_scatter: the same over the slot counts).
+// k_prefix: exclusive prefix over the per-block survivor counts (each block
+// sums its predecessors; <= a few thousand ints from L2), then the stable
+// scatter of continue_idx and the active-row -> state-row map.
 // ---------------------------------------------------------------------------
-struct RowFate {
-    int pos;    // position among the survivors, -1: stopped in this step
-    int dest;   // state row written for it
-};
-// what the step decided for active row `row`, from the one word k_advance left
-__device__ __forceinline__ RowFate row_fate(const EnvParams &P, int row, int total, int order) {
-    const int rs = P.rank[row];
-    const bool stop = rs < 0;
-    const int pos = P.block_before[row >> 8] + (rs & 0x7fffffff);
-    int dest = row;
-    if (order == TTL_ORDER_PARTITION) dest = stop ? total + (row - pos) : pos;
-    return RowFate{stop ? -1 : pos, dest};
+__global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
+                                                  const int *__restrict__ idx,
+                                                  int *__restrict__ idx_next,
+                                                  const int *__restrict__ proc,
+                                                  int n_active, int n_blocks,
+                                                  int order, int n_pts,
+                                                  int *__restrict__ host_word, int seq) {
+    if (proc) {
+        // first half of the processing-order compaction (slot order, same
+        // grid): which slots survive, ranked inside their block
+        const int j = blockIdx.x * BLOCK + threadIdx.x;
+        const bool active = j < n_active;
+        const bool keep = active && P.stop[proc[active ? j : 0]] == 0;
+        block_ranks(P.proc_rank, P.proc_counts, j, active, keep);
+    }
+    __shared__ int red[2][BLOCK / 64];
+    int before = 0, total = 0;
+    for (int b = threadIdx.x; b < n_blocks; b += BLOCK) {
+        const int c = P.block_counts[b];
+        total += c;
+        if (b < (int)blockIdx.x) before += c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_down(before, off);
+        total += __shfl_down(total, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = before;
+        red[1][wave] = total;
+    }
+    __syncthreads();
+    before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        before += red[0][w];
+        total += red[1][w];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.counts[0] = total;
+        P.counts[1] = n_active - total;
+        if (host_word) {
+            // straight into the caller's pinned buffer, sequence number last:
+            // the host polls it (ttl_env_wait_counts) and can queue the next
+            // step while the state gather of this one is still running
+            __hip_atomic_store(host_word + 0, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_word + 1, n_active - total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_word + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_active) return;
+    const int pos = before + P.rank[i];
+    const bool stop = P.stop[i] != 0;
+    const int g = idx[i];
+    if (!stop) idx_next[pos] = g;
+    // ORDER_PARTITION has no separate harvest kernel: record the final length
+    // of the streamlines that just stopped here (tracking_env.py:236)
+    if (stop && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
+    P.surv_pos[i] = stop ? -1 : pos;
+    int dest = i;
+    if (order == TTL_ORDER_PARTITION) dest = stop ? total + (i - pos) : pos;
+    P.row_dest[i] = dest;
+    *reinterpret_cast<int2 *>(P.pos_dest + 2 * (size_t)i) = int2{stop ? -1 : pos, dest};
 }
 
-static_assert(BLOCK == 256, "row_fate: rows per k_advance workgroup = 1 << 8");
-
+// ---------------------------------------------------------------------------
+// Processing order of the state gather.  Row order (continue_idx order) is
+// fixed by the reference, but WHICH rows a workgroup gathers is free: proc[j]
+// lists the active rows sorted by the 8^3-voxel brick of their seed, so that a
+// workgroup -- and its neighbours in time on the same XCD -- fetch voxels that
+// are already in L2 instead of going to the Infinity Cache / HBM for each
+// streamline separately.  Each step proc is compacted (stable, in proc order)
+// and renumbered with the survivors' new row ids.
+// ---------------------------------------------------------------------------
 // low 6 bits of v spread to every third bit (Morton interleave helper)
 __device__ __forceinline__ unsigned spread3(unsigned v) {
     v &= 63u;
@@ -658,76 +584,61 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {
     return v;
 }
 
-// Processing order of the state gather.  Row order (continue_idx order) is
-// fixed by the reference, but WHICH rows a workgroup gathers is free: proc
-// lists the active rows sorted by the 8^3-voxel brick of their seed, so that a
-// workgroup -- and its neighbours in time on the same XCD -- fetch voxels that
-// are already in L2 instead of going to the Infinity Cache / HBM for each
-// streamline separately.  The order is kept in segments (ttl_internal.h); each
-// step every segment is compacted (stable, in its own order) and renumbered
-// with the survivors' new row ids.
-__global__ __launch_bounds__(BLOCK) void k_tail(EnvParams P, const int *__restrict__ idx,
-                                                int *__restrict__ idx_next, int n_active,
-                                                int n_row_blocks, int order, int n_pts,
-                                                const int *__restrict__ proc,
-                                                int *__restrict__ proc_next,
-                                                const int *__restrict__ seg_in,
-                                                int *__restrict__ seg_out, int local_sort) {
-    const int total = P.counts[0];
-    if ((int)blockIdx.x < n_row_blocks) {
-        // ---- rows: coalesced per-row outputs ----
-        const int i = blockIdx.x * BLOCK + threadIdx.x;
-        if (i >= n_active) return;
-        const RowFate f = row_fate(P, i, total, order);
-        const int g = idx[i];
-        if (f.pos >= 0) idx_next[f.pos] = g;
-        // ORDER_PARTITION has no separate harvest kernel: record the final
-        // length of the streamlines that just stopped here (tracking_env.py:236)
-        if (f.pos < 0 && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
-        P.surv_pos[i] = f.pos;
-        P.row_dest[i] = f.dest;
-        return;
-    }
-    // ---- slots: one workgroup per segment; slot t of segment s (t < seg_in[s])
-    // holds active row proc[s * SEG + t] ----
+__global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
+                                                        const int *__restrict__ idx,
+                                                        const int *__restrict__ proc,
+                                                        int *__restrict__ proc_next,
+                                                        int n_active, int n_blocks,
+                                                        int local_sort) {
     __shared__ int red[BLOCK / 64];
     __shared__ unsigned s_key[BLOCK];
     __shared__ int s_pos[BLOCK];
-    const int seg = blockIdx.x - n_row_blocks;
-    const int SEG = P.seg_slots;
-    const size_t base = (size_t)seg * SEG;
-    const int cnt = seg_in[seg];
-    const bool active = (int)threadIdx.x < cnt;
+    int before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) before += P.proc_counts[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = before;
+    __syncthreads();
+    before = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) before += red[w];
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = j < n_active;
     float4 hd = float4{0.f, 0.f, 0.f, 0.f};
-    RowFate f{-1, 0};
+    int2 pd = int2{-1, 0};
     if (active) {
-        const int row = proc[base + threadIdx.x];
-        // two scattered loads per slot: the head record (its .w carries
-        // idx[row]) and the row's rank word.  Everything this step's state
-        // gather needs to know about the slot is resolved here, one thread per
-        // slot, so that the gather (12 lanes per slot) starts from two
-        // coalesced loads
+        const int row = proc[j];
+        pd = *reinterpret_cast<const int2 *>(P.pos_dest + 2 * (size_t)row);
+        // two scattered loads per slot: the packed {surv_pos, row_dest} above
+        // and the head record, whose .w already carries idx[row]
         hd = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
-        f = row_fate(P, row, total, order);
     }
-    // Local re-sort: the slots of this segment are put in Morton order of the
-    // voxel their streamline sits in now.  The global order (8^3 bricks,
+    if (!local_sort) {
+        if (!active) return;
+        if (pd.x >= 0) proc_next[before + P.proc_rank[j]] = pd.x;
+        // everything this step's state gather needs to know about slot j, in
+        // slot order: one thread per slot resolves the row indirections here,
+        // so the gather (12 lanes per slot) starts from two coalesced loads
+        *reinterpret_cast<float4 *>(P.slot_head + 4 * (size_t)j) = hd;
+        P.slot_dest[j] = pd.y;
+        return;
+    }
+    // Local re-sort: the 256 slots of this block are put in Morton order of
+    // the voxel their streamline sits in now.  The global order (8^3 bricks,
     // rebuilt every few steps) decays slowly; the order INSIDE a brick decays
     // within two steps (a step is 0.75 voxel) and decides how many of a wave's
-    // five streamlines share voxel records.  A 256-key rank sort in LDS; live
-    // slots first (dead threads carry the largest keys).
-    unsigned key = 0xFFFFFF00u | threadIdx.x;
+    // five streamlines share voxel records.  A block's slots stay the block's
+    // (the kept-slot count per block is permutation invariant), so this is a
+    // 256-key rank sort in LDS, no extra launch.
+    unsigned key = 0xFFFFFFFFu;
     if (active) {
-        key = threadIdx.x;
-        if (local_sort) {
-            const unsigned vx = (unsigned)(int)fminf(fmaxf(floorf(hd.x), 0.0f), 1023.0f);
-            const unsigned vy = (unsigned)(int)fminf(fmaxf(floorf(hd.y), 0.0f), 1023.0f);
-            const unsigned vz = (unsigned)(int)fminf(fmaxf(floorf(hd.z), 0.0f), 1023.0f);
-            // bits above the low 6 per axis first (coarse), then the Morton code
-            const unsigned coarse = (((vx >> 6) & 3u) << 4) | (((vy >> 6) & 3u) << 2) | ((vz >> 6) & 3u);
-            const unsigned m = (spread3(vx) << 2) | (spread3(vy) << 1) | spread3(vz);
-            key = ((coarse << 18 | m) << 8) | threadIdx.x;      // unique inside the block, < 2^30
-        }
+        const unsigned vx = (unsigned)(int)fminf(fmaxf(floorf(hd.x), 0.0f), 1023.0f);
+        const unsigned vy = (unsigned)(int)fminf(fmaxf(floorf(hd.y), 0.0f), 1023.0f);
+        const unsigned vz = (unsigned)(int)fminf(fmaxf(floorf(hd.z), 0.0f), 1023.0f);
+        // bits above the low 6 per axis first (coarse), then the Morton code
+        const unsigned coarse = (((vx >> 6) & 3u) << 4) | (((vy >> 6) & 3u) << 2) | ((vz >> 6) & 3u);
+        const unsigned m = (spread3(vx) << 2) | (spread3(vy) << 1) | spread3(vz);
+        key = ((coarse << 18 | m) << 8) | threadIdx.x;      // unique inside the block
     }
     s_key[threadIdx.x] = key;
     __syncthreads();
@@ -738,15 +649,15 @@ __global__ __launch_bounds__(BLOCK) void k_tail(EnvParams P, const int *__restri
         const uint4 q = k4[t];                 // same address in every lane: broadcast
         rank += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
     }
-    // sorted position `rank` of this segment receives this slot's record
+    // sorted position `rank` of this block receives this slot's record
     if (active) {
-        const size_t o = base + rank;
+        const size_t o = (size_t)blockIdx.x * BLOCK + rank;
         *reinterpret_cast<float4 *>(P.slot_head + 4 * o) = hd;
-        P.slot_dest[o] = f.dest;
+        P.slot_dest[o] = pd.y;
     }
-    s_pos[rank] = active ? f.pos : -1;           // surv_pos (or -1) in sorted order
+    s_pos[rank] = active ? pd.x : -1;            // surv_pos (or -1) in sorted order
     __syncthreads();
-    // next step's segment: the survivors, in this sorted order
+    // next step's order: the survivors, in this sorted order
     const int pos = s_pos[threadIdx.x];
     const bool keep = pos >= 0;
     const unsigned long long mk = __ballot(keep);
@@ -754,28 +665,11 @@ __global__ __launch_bounds__(BLOCK) void k_tail(EnvParams P, const int *__restri
     const int below = __popcll(mk & ((1ull << lane) - 1ull));
     if (lane == 0) red[wave] = __popcll(mk);
     __syncthreads();
-    int wave_before = 0, kept = 0;
+    int wave_before = 0;
 #pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) {
+    for (int w = 0; w < BLOCK / 64; ++w)
         if (w < wave) wave_before += red[w];
-        kept += red[w];
-    }
-    if (keep) proc_next[base + wave_before + below] = pos;
-    if (threadIdx.x == 0) seg_out[seg] = kept;
-}
-
-// a dense order of n rows as segments: every segment full but the last
-__global__ void k_seg_init(int *__restrict__ seg_cnt, int n_seg, int n, int seg_slots) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n_seg) seg_cnt[s] = min(seg_slots, n - s * seg_slots);
-}
-
-// the survivor count of a step whose ranks nobody had to redo (the two-call
-// step with no external stop bits): pinned words from P.counts
-__global__ void k_publish_counts(EnvParams P, int *__restrict__ host_word, int seq) {
-    __hip_atomic_store(host_word + 0, P.counts[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_word + 1, P.counts[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_word + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (keep) proc_next[before + wave_before + below] = pos;
 }
 
 // stopping flags of caller-supplied tails (n_pts points per streamline)
@@ -839,7 +733,6 @@ __global__ __launch_bounds__(BLOCK) void k_reset(EnvParams P, int *idx,
                                                  const float *__restrict__ seeds,
                                                  int n) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i == 0) P.counts[TTL_SCAN_TICKET] = 0;      // a launch that died mid-way leaves no debt
     if (i >= n) return;
     float *h = P.hist + (size_t)i * (size_t)(P.max_nb_steps + 1) * 3;
     h[0] = seeds[(size_t)i * 3 + 0];
@@ -1009,12 +902,7 @@ struct ttl_env {
     int last_order;
     int last_n;      // n_active of the pending step
     uint8_t *last_done;  // done_out of the pending step (k_restop updates it)
-    int *proc[2];        // processing order of the state gather, double buffered, in segments
-    int *seg_cnt[2];     // live slots per segment of proc[.]
-    int proc_nseg;       // segments of the current order (fixed between two global refreshes)
-    int tail_small;      // the pending step takes the one-launch tail (decided at step_begin)
-    int *pend_host_word; // pinned words the pending step reports to (device address) and its
-    int pend_seq;        // sequence number, when k_advance itself publishes the count
+    int *proc[2];        // processing order of the state gather, double buffered
     char *order_ws;      // scratch of the in-library order refresh (ttl_order.hip)
     size_t order_ws_bytes;
     int proc_cur;        // which proc buffer is current
@@ -1033,7 +921,7 @@ struct ttl_env {
     hipStream_t poll_stream;
     int fuse_small;        // batches <= 16384 rows: one launch for prefix + gather
     int poll_counts;       // counts written by the kernel into the pinned buffer (TTL_POLL_COUNTS)
-    int local_sort;        // k_slots re-sorts each segment's slots by current voxel
+    int local_sort;        // k_proc_scatter re-sorts each block's slots by current voxel
     int n_exact;           // n_active is the exact survivor count (read back)
     int fr_cap;            // > 0: free-running steps are being enqueued for this many rows
     int *fr_host_word;     // device address of the pinned words a free-running step reports to
@@ -1063,17 +951,13 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     const size_t n = (size_t)n_max;
     const size_t nb = (n + BLOCK - 1) / BLOCK + 1;
     size_t b = 0;
-    const size_t ns = n + BLOCK;              // slot arrays: segments are stored at their stride
     b += align_up(n, 256);                    // stop
-    b += 3 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest
-    b += 2 * align_up(ns * sizeof(int), 256); // proc x2
-    b += align_up(n * 4 * sizeof(float), 256);  // head
-    b += align_up(ns * 4 * sizeof(float), 256); // slot_head
+    b += 6 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest, proc_rank, proc x2
+    b += 2 * align_up(n * 4 * sizeof(float), 256); // head, slot_head
     b += align_up(n * 8 * sizeof(float), 256); // last2
-    b += align_up(ns * sizeof(int), 256);     // slot_dest
-    b += 2 * align_up((nb + 1) * sizeof(int), 256); // block_counts, block_before
-    b += align_up((nb + 1) * sizeof(unsigned long long), 256); // block_tagged
-    b += 2 * align_up((n / 240 + 2) * sizeof(int), 256); // seg_cnt x2 (segments are >= 240 slots)
+    b += align_up(n * 2 * sizeof(int), 256);   // pos_dest
+    b += align_up(n * sizeof(int), 256);      // slot_dest
+    b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
     b += ttl_detail_order_workspace_bytes(n); // order refresh scratch
     return b;
@@ -1311,24 +1195,17 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.rank = (int *)w;            w += align_up(n * sizeof(int), 256);
     P.surv_pos = (int *)w;        w += align_up(n * sizeof(int), 256);
     P.row_dest = (int *)w;        w += align_up(n * sizeof(int), 256);
-    const size_t ns = n + BLOCK;
-    P.block_counts = (int *)w;    w += align_up((nb + 1) * sizeof(int), 256);
-    P.block_before = (int *)w;    w += align_up((nb + 1) * sizeof(int), 256);
-    P.block_tagged = (unsigned long long *)w;  w += align_up((nb + 1) * sizeof(unsigned long long), 256);
-    e->proc[0] = (int *)w;        w += align_up(ns * sizeof(int), 256);
-    e->proc[1] = (int *)w;        w += align_up(ns * sizeof(int), 256);
-    e->seg_cnt[0] = (int *)w;     w += align_up((n / 240 + 2) * sizeof(int), 256);
-    e->seg_cnt[1] = (int *)w;     w += align_up((n / 240 + 2) * sizeof(int), 256);
+    P.block_counts = (int *)w;    w += align_up(nb * sizeof(int), 256);
+    P.proc_rank = (int *)w;       w += align_up(n * sizeof(int), 256);
+    P.proc_counts = (int *)w;     w += align_up(nb * sizeof(int), 256);
+    e->proc[0] = (int *)w;        w += align_up(n * sizeof(int), 256);
+    e->proc[1] = (int *)w;        w += align_up(n * sizeof(int), 256);
     P.head = (float *)w;          w += align_up(n * 4 * sizeof(float), 256);
-    P.slot_head = (float *)w;     w += align_up(ns * 4 * sizeof(float), 256);
+    P.slot_head = (float *)w;     w += align_up(n * 4 * sizeof(float), 256);
     P.last2 = (float *)w;         w += align_up(n * 8 * sizeof(float), 256);
-    P.slot_dest = (int *)w;       w += align_up(ns * sizeof(int), 256);
+    P.pos_dest = (int *)w;        w += align_up(n * 2 * sizeof(int), 256);
+    P.slot_dest = (int *)w;       w += align_up(n * sizeof(int), 256);
     P.counts = (int *)w;          w += 256;
-    P.seg_slots = ttl_detail_seg_slots(d.coef_pitch);
-    e->proc_nseg = 0;
-    e->tail_small = 0;
-    e->pend_host_word = nullptr;
-    e->pend_seq = 0;
     e->order_ws = w;
     e->order_ws_bytes = ttl_detail_order_workspace_bytes(n);
     e->length = 0;
@@ -1342,6 +1219,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->use_proc = 0;
     e->state_kernel = 4;
     if (const char *v = getenv("TTL_STATE_KERNEL")) e->state_kernel = atoi(v);
+    P.slot_rec = e->state_kernel != 2;
     P.xcd_remap = 1;
     if (const char *v = getenv("TTL_XCD_REMAP")) P.xcd_remap = atoi(v);
     P.xcd_rot = 0;
@@ -1447,17 +1325,6 @@ int ttl_scripted_actions(const float *state, int64_t state_pitch, int32_t dir_of
     return TTL_OK;
 }
 
-// the dense order of n rows in env->proc[which] becomes segments: all full but
-// the last
-static int seg_init(ttl_env *env, int which, int n, hipStream_t s) {
-    const int seg = env->P.seg_slots;
-    env->proc_nseg = (n + seg - 1) / seg;
-    hipLaunchKernelGGL(k_seg_init, dim3((env->proc_nseg + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s,
-                       env->seg_cnt[which], env->proc_nseg, n, seg);
-    HIP_TRY(hipGetLastError());
-    return TTL_OK;
-}
-
 int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
                   const int32_t *processing_order, float *state_out,
                   int64_t state_pitch, void *hip_stream) {
@@ -1493,14 +1360,9 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
         HIP_TRY(hipMemcpyAsync(env->proc[0], processing_order, (size_t)n * sizeof(int32_t),
                                hipMemcpyDeviceToDevice, s));
     }
-    if (env->use_proc) {
-        const int rc = seg_init(env, 0, n, s);
-        if (rc != TTL_OK) return rc;
-    }
-    // the first state rows: the order is still dense here (no slot records yet)
     return ttl_detail_launch_state(env->P, env->state_kernel, nullptr, nullptr,
-                                   env->use_proc ? env->proc[0] : nullptr, nullptr, n, 1,
-                                   state_out, state_pitch, s);
+                                   env->use_proc ? env->proc[0] : nullptr, n, 1, state_out,
+                                   state_pitch, s);
 }
 
 // side-stream copy of {n_continue, n_stopped} to the caller's pinned buffer,
@@ -1522,53 +1384,9 @@ static hipError_t ttl_copy_counts(ttl_env *env, int32_t *host_counts, hipStream_
     return hipSuccess;
 }
 
-// Where the step's survivor count goes: straight into the caller's pinned
-// buffer ({n_continue, n_stopped, sequence number}, written by the kernel that
-// computes it) when that buffer is device-visible -- no side stream, no copy
-// kernel waiting for free CUs behind the gather, no API calls between the
-// step's launches; the host polls the sequence word.  Returns the device
-// address of the words (null: not device-visible, or TTL_POLL_COUNTS=0) and a
-// fresh sequence number.
-static int *host_word_for(ttl_env *env, int32_t *host_counts, int *seq_out) {
-    *seq_out = 0;
-    if (!host_counts || !env->poll_counts) return nullptr;
-    if (env->host_probe != host_counts) {
-        void *dev = nullptr;
-        env->host_probe = host_counts;
-        env->host_dev = nullptr;
-        if (hipHostGetDevicePointer(&dev, host_counts, 0) == hipSuccess)
-            env->host_dev = static_cast<int *>(dev);
-        else
-            (void)hipGetLastError();      // not pinned: copy path
-    }
-    // sequence numbers carry bit 30: word [2] of the same pinned buffer is
-    // the "steps done" counter of a free-running episode (small values), and
-    // a leftover count must never read as this step's sequence number
-    static std::atomic<unsigned> g_seq{1};
-    *seq_out = (int)((g_seq.fetch_add(1, std::memory_order_relaxed) & 0x3fffffffu) | 0x40000000u);
-    return env->host_dev;
-}
-
-// epoch of a scanning launch (k_advance / k_restop): nonzero, fresh per launch
-static int next_epoch() {
-    static std::atomic<unsigned> g_epoch{1};
-    unsigned e = g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x7fffffffu;
-    if (e == 0) e = g_epoch.fetch_add(1, std::memory_order_relaxed) & 0x7fffffffu;
-    return (int)e;
-}
-
-static void expect_polled_counts(ttl_env *env, int32_t *host_counts, int seq, hipStream_t s) {
-    env->counts_pending = 2;
-    env->host_counts = host_counts;
-    env->poll_seq = seq;
-    env->poll_stream = s;
-}
-
-// first half of a step; host_counts != nullptr: the caller of the one-call
-// ttl_env_step() -- k_advance's last workgroup can then publish the count
-static int step_begin(ttl_env *env, const float *actions, const double *noise,
-                      int32_t n_active, double *reward_out, uint8_t *done_out,
-                      int32_t *host_counts, void *hip_stream) {
+int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
+                       int32_t n_active, double *reward_out, uint8_t *done_out,
+                       void *hip_stream) {
     if (!env || !actions || !done_out)
         return fail(TTL_ERR_INVALID, "ttl_env_step: null argument");
     if (env->length < 1) return fail(TTL_ERR_STATE, "ttl_env_step: reset first");
@@ -1587,43 +1405,21 @@ static int step_begin(ttl_env *env, const float *actions, const double *noise,
     const int *idx = env->cur ? d.idx_b : d.idx_a;
     const int L = env->length;
     const int nb = (n_active + BLOCK - 1) / BLOCK;
-    // a few thousand streamlines fit the caches in any order: stop paying for
-    // the processing order in the episode's tail (from 16 384 rows down the
-    // one-launch tail takes over)
-    const bool can_fuse = env->fuse_small && ttl_detail_can_fuse_tail(env->P, n_active);
-    if (env->use_proc && (n_active < 8192 || can_fuse)) env->use_proc = 0;
-    env->tail_small = !env->use_proc && can_fuse && env->state_kernel != 0;
-    // large batches: the last workgroup of k_advance scans the per-workgroup
-    // counts and hands the survivor count to the host
-    // (a fresh nonzero epoch per scanning launch tags the count granules)
-    const int scan = env->tail_small ? 0 : next_epoch();
-    int seq = 0;
-    int *host_word = scan ? host_word_for(env, host_counts, &seq) : nullptr;
-    env->pend_host_word = host_word;
-    env->pend_seq = seq;
     prof_mark(env, 0, 0, s);
 #define TTL_LAUNCH_ADVANCE(M)                                                  \
     hipLaunchKernelGGL((k_advance<M>), dim3(nb), dim3(BLOCK), 0, s, env->P, idx, \
-                       actions, noise, n_active, L, reward_out, done_out, scan, \
-                       host_word, seq)
+                       actions, noise, n_active, L, reward_out, done_out)
     if (d.mode == TTL_MODE_F32) TTL_LAUNCH_ADVANCE(TTL_MODE_F32);
     else if (d.mode == TTL_MODE_F64DIR) TTL_LAUNCH_ADVANCE(TTL_MODE_F64DIR);
     else TTL_LAUNCH_ADVANCE(TTL_MODE_F32NORM);
 #undef TTL_LAUNCH_ADVANCE
     prof_mark(env, 0, 1, s);
     HIP_TRY(hipGetLastError());
-    if (host_word) expect_polled_counts(env, host_counts, seq, s);
     env->length = L + 1;
     env->stepped = 2;          // advanced, not yet committed
     env->last_n = n_active;
     env->last_done = done_out;
     return TTL_OK;
-}
-
-int ttl_env_step_begin(ttl_env *env, const float *actions, const double *noise,
-                       int32_t n_active, double *reward_out, uint8_t *done_out,
-                       void *hip_stream) {
-    return step_begin(env, actions, noise, n_active, reward_out, done_out, nullptr, hip_stream);
 }
 
 int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
@@ -1645,29 +1441,52 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
     const int n_active = env->last_n;
     const int n_pts = env->length;
     const int nb = (n_active + BLOCK - 1) / BLOCK;
-    const bool small = env->tail_small != 0;
-    // the count already went out with k_advance (one-call step, pinned buffer)?
-    const bool published = env->pend_host_word != nullptr && !extra_flags;
-    int seq = env->pend_seq;
-    int *host_word = env->pend_host_word;
-    if (!published) host_word = host_word_for(env, host_counts, &seq);
     if (extra_flags) {
-        // external stop bits (the oracle criterion): redo the ranks -- and, for
-        // the large-batch tail, the scan and the count the host polls for
         hipLaunchKernelGGL(k_restop, dim3(nb), dim3(BLOCK), 0, s, env->P, idx,
-                           extra_flags, n_active, env->last_done, small ? 0 : next_epoch(),
-                           small ? nullptr : host_word, seq);
-        HIP_TRY(hipGetLastError());
-    } else if (!small && !published && host_word) {
-        // two-call step without external bits: k_advance scanned, nobody told the host
-        hipLaunchKernelGGL(k_publish_counts, dim3(1), dim3(1), 0, s, env->P, host_word, seq);
+                           extra_flags, n_active, env->last_done);
         HIP_TRY(hipGetLastError());
     }
+    // a few thousand streamlines fit the caches in any order: stop paying for
+    // the processing order in the episode's tail (from 16 384 rows down the
+    // one-launch tail below takes over)
+    if (env->use_proc && (n_active < 8192 ||
+                          (env->fuse_small && ttl_detail_can_fuse_tail(env->P, n_active))))
+        env->use_proc = 0;
     const int *proc = env->use_proc ? env->proc[env->proc_cur] : nullptr;
     env->stepped = 1;
     env->last_order = order;
-    if (host_word) expect_polled_counts(env, host_counts, seq, s);
-    if (small) {
+    // The survivor count goes straight into the caller's pinned buffer
+    // ({n_continue, n_stopped, sequence number}, written by the kernel that
+    // computes it) when that buffer is device-visible: no side stream, no copy
+    // kernel waiting for free CUs behind the gather, no API calls between the
+    // step's launches; the host polls the sequence word.
+    int *host_word = nullptr;
+    int seq = 0;
+    if (host_counts && env->poll_counts) {
+        if (env->host_probe != host_counts) {
+            void *dev = nullptr;
+            env->host_probe = host_counts;
+            env->host_dev = nullptr;
+            if (hipHostGetDevicePointer(&dev, host_counts, 0) == hipSuccess)
+                env->host_dev = static_cast<int *>(dev);
+            else
+                (void)hipGetLastError();      // not pinned: copy path below
+        }
+        host_word = env->host_dev;
+        // sequence numbers carry bit 30: word [2] of the same pinned buffer is
+        // the "steps done" counter of a free-running episode (small values), and
+        // a leftover count must never read as this step's sequence number
+        static std::atomic<unsigned> g_seq{1};
+        seq = (int)((g_seq.fetch_add(1, std::memory_order_relaxed) & 0x3fffffffu) | 0x40000000u);
+    }
+    if (host_word) {
+        env->counts_pending = 2;
+        env->host_counts = host_counts;
+        env->poll_seq = seq;
+        env->poll_stream = s;
+    }
+    if (!proc && env->fuse_small && env->state_kernel != 0 &&
+        ttl_detail_can_fuse_tail(env->P, n_active)) {
         // small batch: prefix + compaction + gather in ONE launch
         prof_mark(env, 2, 0, s);
         const int rc = ttl_detail_launch_fused_tail(env->P, idx, idx_next, n_active, order,
@@ -1678,29 +1497,28 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         if (host_counts && !host_word) HIP_TRY(ttl_copy_counts(env, host_counts, s));
         return TTL_OK;
     }
-    if (host_counts && !host_word) {
-        // fallback (buffer not device-visible): ship the count on a side stream;
-        // it is final since k_advance / k_restop
-        HIP_TRY(ttl_copy_counts(env, host_counts, s));
-    }
     prof_mark(env, 1, 0, s);
-    {
-        // one launch: a workgroup per 256 rows (index compaction, row map) and,
-        // with a processing order, a workgroup per segment of it (per-slot
-        // records for the gather, the next step's segment)
-        const int which = env->proc_cur;
-        const int nseg = proc ? env->proc_nseg : 0;
-        hipLaunchKernelGGL(k_tail, dim3(nb + nseg), dim3(BLOCK), 0, s, env->P, idx, idx_next,
-                           n_active, nb, order, n_pts, proc, env->proc[which ^ 1],
-                           env->seg_cnt[which], env->seg_cnt[which ^ 1], env->local_sort);
-    }
+    hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
+                       proc, n_active, nb, order, n_pts, host_word, seq);
     prof_mark(env, 1, 1, s);
     HIP_TRY(hipGetLastError());
+    if (host_counts && !host_word) {
+        // fallback (buffer not device-visible): ship the count on a side stream
+        // as soon as k_prefix has run
+        HIP_TRY(ttl_copy_counts(env, host_counts, s));
+    }
+    if (proc) {
+        // next step's processing order: this one, compacted in its own order
+        // (ranks from k_prefix) and renumbered with the survivors' new row
+        // ids; plus this step's per-slot records for the gather
+        hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, proc,
+                           env->proc[env->proc_cur ^ 1], n_active, nb,
+                           env->local_sort && env->P.slot_rec);
+        HIP_TRY(hipGetLastError());
+    }
     prof_mark(env, 2, 0, s);
-    const int rc = ttl_detail_launch_state(
-        env->P, env->state_kernel, idx, env->P.row_dest, proc,
-        proc ? env->seg_cnt[env->proc_cur] : nullptr,
-        proc ? env->proc_nseg * env->P.seg_slots : n_active, n_pts, state_out, state_pitch, s);
+    const int rc = ttl_detail_launch_state(env->P, env->state_kernel, idx, env->P.row_dest,
+                                           proc, n_active, n_pts, state_out, state_pitch, s);
     prof_mark(env, 2, 1, s);
     return rc;
 }
@@ -1717,8 +1535,8 @@ int ttl_env_step(ttl_env *env, const float *actions, const double *noise,
         if (state_pitch < width)
             return fail(TTL_ERR_INVALID, "ttl_env_step: state_pitch too small");
     }
-    const int rc = step_begin(env, actions, noise, n_active, reward_out, done_out,
-                              host_counts, hip_stream);
+    const int rc = ttl_env_step_begin(env, actions, noise, n_active, reward_out,
+                                      done_out, hip_stream);
     if (rc != TTL_OK) return rc;
     return ttl_env_step_end(env, nullptr, order, state_out, state_pitch,
                             host_counts, hip_stream);
@@ -1790,9 +1608,6 @@ int ttl_env_wait_counts(ttl_env *env) {
     env->counts_pending = 0;
     // the handle now knows the exact number of survivors: the next step must
     // be launched for exactly that many rows
-    if (env->host_counts && env->host_counts[0] < 0)
-        return fail(TTL_ERR_HIP, "ttl_env_wait_counts: the step's survivor scan never saw "
-                                 "every workgroup's count (GPU memory fault?)");
     if (env->host_counts && !env->stepped) {
         env->n_active = env->host_counts[0];
         env->n_exact = 1;
@@ -1938,8 +1753,6 @@ int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
                     n, env->n_active);
     HIP_TRY(hipMemcpyAsync(env->proc[env->proc_cur], order, (size_t)n * sizeof(int32_t),
                            hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
-    const int rc = seg_init(env, env->proc_cur, n, (hipStream_t)hip_stream);
-    if (rc != TTL_OK) return rc;
     env->use_proc = 1;
     return TTL_OK;
 }
@@ -1951,10 +1764,9 @@ int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream) {
     if (!env->n_exact)
         return fail(TTL_ERR_STATE, "ttl_env_refresh_processing_order: survivor count not read back yet");
     const int *idx = env->cur ? env->d.idx_b : env->d.idx_a;
-    int rc = ttl_detail_refresh_order(env->P, idx, env->n_active, env->order_ws,
-                                      env->order_ws_bytes, env->proc[env->proc_cur],
-                                      (hipStream_t)hip_stream);
-    if (rc == TTL_OK) rc = seg_init(env, env->proc_cur, env->n_active, (hipStream_t)hip_stream);
+    const int rc = ttl_detail_refresh_order(env->P, idx, env->n_active, env->order_ws,
+                                            env->order_ws_bytes, env->proc[env->proc_cur],
+                                            (hipStream_t)hip_stream);
     if (rc == TTL_OK) env->use_proc = 1;
     return rc;
 }

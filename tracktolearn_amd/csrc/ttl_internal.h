@@ -54,44 +54,22 @@ struct EnvParams {
     // workspace
     uint8_t *stop;     // [n_max] 1 = stopped in the last step
     float *head;       // [n_max][4] newest point of every active row (row order), .w = bits of idx[row]
+    int *pos_dest;     // [n_max][2] {surv_pos, row_dest} of every active row, packed for k_proc_scatter
     float *last2;      // [n_max][8] per streamline id: {p[L-2], pad, p[L-1], pad}, the two newest points
-    int *rank;         // [n_max] survivors before this row inside its block; sign bit: the row stopped
+    int *rank;         // [n_max] survivors before this row inside its block
     int *surv_pos;     // [n_max] position among survivors, -1 if stopped
     int *row_dest;     // [n_max] state row written for this active row
-    int *block_counts; // [ceil(n_max/BLOCK)] survivors per block of k_advance
-    int *block_before; // [ceil(n_max/BLOCK) + 1] survivors in the blocks before this one (k_advance's last block)
-    unsigned long long *block_tagged; // [ceil(n_max/BLOCK)] {epoch, count} granules of a scanning launch
-    float *slot_head;  // [n_max + 256][4] per slot of the processing order: newest point, .w = bits of idx[row]
-    int *slot_dest;    // [n_max + 256] per slot of the processing order: row_dest[row]
-    int seg_slots;     // slots per segment of the processing order (see TTL_SEG_* below)
+    int *block_counts; // [ceil(n_max/BLOCK)] survivors per block
+    int *proc_rank;    // [n_max] rank of a kept slot of the processing order
+    int *proc_counts;  // [ceil(n_max/BLOCK)] kept slots per block
+    float *slot_head;  // [n_max][4] per slot of the processing order: newest point, .w = bits of idx[row]
+    int *slot_dest;    // [n_max] per slot of the processing order: row_dest[row]
+    int slot_rec;      // the gather reads the slot records (0: resolves proc -> idx/row_dest/head itself)
     int store_flavour; // cache policy of the state-row stores (TTL_STORE_FLAVOUR, see store16)
     int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
     int xcd_rot;       // XCD x gathers range (x + xcd_rot) & 7 of the processing order
-    int *counts;       // {n_continue, n_stopped}; 64 ints: the free-running step's words and
-                       // the arrival ticket of k_advance's blocks (TTL_SCAN_TICKET) live here too
+    int *counts;       // {n_continue, n_stopped}; 64 ints: the free-running step's words live here too
 };
-
-// Processing order in SEGMENTS (round 3).  The order of the state gather is
-// kept as segments of seg_slots slots (the largest multiple of the gather's
-// rows per workgroup that fits a 256-thread workgroup: 240 for 12 lanes per
-// streamline, 256 otherwise), stored at stride seg_slots: segment s owns
-// proc[s * seg_slots ...] and holds seg_cnt[s] live slots at its front.  A
-// streamline that stops leaves its segment; nothing moves between segments
-// until the next global refresh (ttl_order.hip) rebuilds a dense order.  So
-// compacting the order needs no prefix over workgroups -- one workgroup per
-// segment does it alone (k_slots) -- and the gather's workgroups, each inside
-// one segment, skip the slots past seg_cnt.
-__host__ __device__ inline int ttl_detail_lanes_per_streamline(int coef_pitch) {
-    const int c4 = coef_pitch >> 2;
-    return c4 <= 4 ? 4 : c4 <= 8 ? 8 : c4 <= 12 ? 12 : c4 <= 16 ? 16 : 32;
-}
-__host__ __device__ inline int ttl_detail_seg_slots(int coef_pitch) {
-    const int rows = (TTL_BLOCK / 64) * (64 / ttl_detail_lanes_per_streamline(coef_pitch));
-    return TTL_BLOCK / rows * rows;
-}
-// int offset into EnvParams::counts of the arrival ticket of k_advance's /
-// k_restop's workgroups (the last one to arrive scans the per-block counts)
-constexpr int TTL_SCAN_TICKET = 32;
 
 // free-running step (ttl_env_freerun_*): int offsets into EnvParams::counts of
 // {n_active, length, cur, steps done} -- live (between steps) and the snapshot
@@ -122,12 +100,9 @@ inline size_t ttl_detail_sh_records(const EnvParams &P) {
 
 // ttl_state.hip: gathers the state rows of `n_rows` active rows (a step when
 // idx != nullptr, the reset otherwise) on stream s
-// seg_cnt != nullptr (a step in processing order): n_rows = segments *
-// P.seg_slots slots, of which segment s has seg_cnt[s] live ones; the gather
-// reads the per-slot records k_slots left (P.slot_head / P.slot_dest)
 int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx,
-                            const int *row_dest, const int *proc, const int *seg_cnt,
-                            int n_rows, int L, float *out, int64_t pitch, hipStream_t s);
+                            const int *row_dest, const int *proc, int n_rows, int L,
+                            float *out, int64_t pitch, hipStream_t s);
 // ttl_state.hip: the small-batch step tail (prefix + compaction + gather) in
 // one launch; host_word = device-visible pinned {n_continue, n_stopped, seq}
 // or null

@@ -25,8 +25,8 @@ constexpr int BLOCK = TTL_BLOCK;
 template <int LPS>
 __global__ __launch_bounds__(BLOCK) void k_state(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
-    const int *__restrict__ proc, const int *__restrict__ seg_cnt, int n_rows, int L,
-    float *__restrict__ out, long long pitch) {
+    const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
+    long long pitch) {
     constexpr int GPW = 64 / LPS;              // streamlines per wave
     constexpr int ROWS = (BLOCK / 64) * GPW;
     const int lane = threadIdx.x & 63;
@@ -34,18 +34,9 @@ __global__ __launch_bounds__(BLOCK) void k_state(
     const int slot = blockIdx.x * ROWS + (threadIdx.x >> 6) * GPW + grp;
     const int sub = lane - grp * LPS;
     if (grp >= GPW || slot >= n_rows) return;
-    int g, r;
-    if (seg_cnt) {      // a step in processing order: the slot records of k_slots
-        constexpr int SEG = BLOCK / ROWS * ROWS;        // == P.seg_slots
-        const int seg = (blockIdx.x * ROWS) / SEG;      // a workgroup sits in one segment
-        if (slot - seg * SEG >= seg_cnt[seg]) return;
-        g = __float_as_int(P.slot_head[4 * (size_t)slot + 3]);
-        r = P.slot_dest[slot];
-    } else {
-        const int row = proc ? proc[slot] : slot;
-        g = idx ? idx[row] : row;
-        r = row_dest ? row_dest[row] : row;
-    }
+    const int row = proc ? proc[slot] : slot;
+    const int g = idx ? idx[row] : row;
+    const int r = row_dest ? row_dest[row] : row;
     const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
     const float px = h[(L - 1) * 3 + 0];
     const float py = h[(L - 1) * 3 + 1];
@@ -426,8 +417,8 @@ __device__ __forceinline__ void state_row_dd(const EnvParams &P, float px, float
 template <int LPS, int MINW, bool LOOP, bool MERGE_TAIL>
 __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
-    const int *__restrict__ proc, const int *__restrict__ seg_cnt, int n_rows, int L,
-    float *__restrict__ out, long long pitch) {
+    const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
+    long long pitch) {
     // LPS lanes per streamline, 64 / LPS streamlines per wave (LPS need not be
     // a power of two: with 12 float4 columns per record a wave serves 5
     // streamlines on 60 lanes instead of 4 on 48)
@@ -460,13 +451,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     if (grp >= GPW || slot >= n_rows) return;
     int row, g, r;
     float px, py, pz;
-    const bool slot_records = seg_cnt != nullptr;   // a step in processing order
-    if (slot_records) {     // k_slots resolved row, idx[row], row_dest[row]
-        // the order is kept in segments (ttl_internal.h); a workgroup sits inside
-        // one segment and skips the slots its streamlines have left
-        constexpr int SEG = BLOCK / ROWS * ROWS;        // == P.seg_slots
-        const int seg = (blk * ROWS) / SEG;
-        if (slot - seg * SEG >= seg_cnt[seg]) return;
+    const bool slot_records = proc && idx && P.slot_rec;   // a step in processing order
+    if (slot_records) {     // k_proc_scatter resolved row, idx[row], row_dest[row]
         const float4 hp = *reinterpret_cast<const float4 *>(P.slot_head + 4 * (size_t)slot);
         px = hp.x;
         py = hp.y;
@@ -555,7 +541,7 @@ __device__ __forceinline__ void prefix_state_body(
     const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
     const int g = __float_as_int(hp.w);
     const bool stop = P.stop[row] != 0;
-    const int pos = s_before[row >> 8] + (P.rank[row] & 0x7fffffff);
+    const int pos = s_before[row >> 8] + P.rank[row];
     int dest = row;
     if (order == TTL_ORDER_PARTITION) dest = stop ? total + (row - pos) : pos;
     if (sub == 0) {
@@ -655,8 +641,8 @@ int ttl_detail_launch_fused_tail_fr(const EnvParams &P, int *idx_a, int *idx_b, 
 }
 
 int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx,
-                            const int *row_dest, const int *proc, const int *seg_cnt,
-                            int n_rows, int L, float *out, int64_t pitch, hipStream_t s) {
+                            const int *row_dest, const int *proc, int n_rows, int L,
+                            float *out, int64_t pitch, hipStream_t s) {
     const int C4 = P.coef_pitch >> 2;
     // the register-deduplicated kernel needs the shifted points to stay
     // within one cell of the centre: 0 < radius < 1 voxel
@@ -669,15 +655,15 @@ int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx
         const dim3 grid((n_rows + rows_per_block - 1) / rows_per_block);      \
         if (!dedupe)                                                          \
             hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, P, \
-                               idx, row_dest, proc, seg_cnt, n_rows, L, out,  \
+                               idx, row_dest, proc, n_rows, L, out,           \
                                (long long)pitch);                             \
         else if (LPS < 32 && P.n_coef >= 4 && state_kernel != 3)    \
             hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32), (LPS < 32)>), grid, dim3(BLOCK), 0, s, \
-                               P, idx, row_dest, proc, seg_cnt, n_rows, L, out, \
+                               P, idx, row_dest, proc, n_rows, L, out,   \
                                (long long)pitch);                             \
         else                                                                  \
             hipLaunchKernelGGL((k_state_dd<LPS, (LPS >= 32 ? 2 : 4), (LPS >= 32), false>), grid, dim3(BLOCK), 0, s, \
-                               P, idx, row_dest, proc, seg_cnt, n_rows, L, out, \
+                               P, idx, row_dest, proc, n_rows, L, out,   \
                                (long long)pitch);                             \
     } while (0)
     if (C4 <= 4) TTL_LAUNCH_STATE(4);

@@ -55,6 +55,45 @@ class _StepInfo(dict):
         return key == 'continue_idx' or super().__contains__(key)
 
 
+class _LazyStateRows(torch.Tensor):
+    """``step()``'s state rows in the reference's row order (one row per active
+    streamline, continue_idx order), gathered on first use.
+
+    The step writes its state rows survivors first, so that ``harvest()`` --
+    whose result the policy needs at once -- is a view and copies nothing.  The
+    reference's own tracking loop never looks at the rows ``step()`` returns
+    (rl.py:95-101 overwrites them with ``harvest()``'s); its training loop does
+    (ddpg.py: the replay buffer's ``next_state``).  This tensor serves both: it
+    has the shape, dtype and device of the real thing and becomes
+    ``rows[row_dest]`` (one gather, what ``harvest()`` used to pay as a copy)
+    the first time any torch operation touches it."""
+
+    @staticmethod
+    def __new__(cls, rows, row_dest):
+        t = torch.Tensor._make_wrapper_subclass(
+            cls, (int(row_dest.shape[0]), int(rows.shape[1])), dtype=rows.dtype,
+            device=rows.device)
+        t._rows, t._row_dest, t._value = rows, row_dest, None
+        return t
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self._rows.index_select(0, self._row_dest.long())
+            self._rows = self._row_dest = None
+        return self._value
+
+    def __repr__(self):
+        return f'_LazyStateRows(shape={tuple(self.shape)}, materialized={self._value is not None})'
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+
+        def real(x):
+            return x.materialize() if isinstance(x, _LazyStateRows) else x
+        return func(*tree_map(real, args), **tree_map(real, kwargs or {}))
+
+
 class _FreeRun:
     """The captured graph of one free-running step (policy + env launches) and
     the fixed buffers it works on."""
@@ -272,7 +311,8 @@ class TrackingEnvironment(BaseEnv):
         self._refresh_processing_order()
         # the device-resident loop writes into the placed ring (env.py); step()
         # hands out fresh tensors as the reference does
-        state = self._ring_state(n) if order == _lib.ORDER_PARTITION else self._new_state(n)
+        state = self._ring_state(n) if order == _lib.ORDER_PARTITION and not host_outputs \
+            else self._new_state(n)
         done = torch.empty(n, dtype=torch.uint8, device=self.device)
         reward = None
         if self.compute_reward:
@@ -370,9 +410,15 @@ class TrackingEnvironment(BaseEnv):
         N_total when rewards are off, tracking_env.py:204); ``dones`` bool
         numpy; ``info`` = {'continue_idx', 'reward_info'}.
         """
-        state, reward, done = self._launch_step(actions, _lib.ORDER_ACTIVE,
-                                                host_outputs=True)
+        lazy = self.lazy_step_state
+        state, reward, done = self._launch_step(
+            actions, _lib.ORDER_PARTITION if lazy else _lib.ORDER_ACTIVE, host_outputs=True)
         n = self._pending['n']
+        if lazy:
+            # the rows were written survivors first (harvest() will be a view);
+            # the reference's row order is one gather away, paid only by callers
+            # that look (the map is copied: the library rewrites it every step)
+            state = _LazyStateRows(state, self._row_dest_view(n).clone())
         if self._pending['early']:
             # dones / reward were copied to pinned memory right behind the
             # step's first kernel: wait for those copies only
@@ -406,6 +452,12 @@ class TrackingEnvironment(BaseEnv):
             z = self._zero_reward_np = np.zeros(n)
             z.flags.writeable = False       # shared between steps: writing it raises
         return z
+
+    #: ``step()`` returns its state rows as a ``_LazyStateRows`` (gathered into the
+    #: reference's row order on first use) and ``harvest()`` copies nothing;
+    #: False (``TTL_LAZY_STEP_STATE=0``): the rows are written in the reference's
+    #: order and ``harvest()`` copies the survivors' rows
+    lazy_step_state = os.environ.get('TTL_LAZY_STEP_STATE', '1') != '0'
 
     def step_device(self, actions):
         """Device-resident step: no host copy, no sync.  ``state`` rows are
