@@ -1237,6 +1237,12 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->poll_stream = nullptr;
     e->fuse_small = 1;
     if (const char *v = getenv("TTL_FUSE_SMALL")) e->fuse_small = atoi(v);
+    P.fuse_max_rows = 64 * BLOCK;
+    if (const char *v = getenv("TTL_FUSE_MAX_ROWS")) {
+        const int rows = atoi(v);
+        P.fuse_max_rows = rows < BLOCK ? BLOCK : rows > TTL_FUSE_MAX_BLOCKS * BLOCK
+                                                     ? TTL_FUSE_MAX_BLOCKS * BLOCK : rows;
+    }
     e->local_sort = 1;
     if (const char *v = getenv("TTL_LOCAL_SORT")) e->local_sort = atoi(v);
     e->poll_counts = 1;
@@ -1640,7 +1646,7 @@ int ttl_env_freerun_begin(ttl_env *env, int32_t *host_counts, void *hip_stream) 
     if (env->n_active < 1) return fail(TTL_ERR_STATE, "ttl_env_freerun_begin: no active streamline");
     if (env->state_kernel == 0 || !ttl_detail_can_fuse_tail(env->P, env->n_active))
         return fail(TTL_ERR_UNSUPPORTED, "ttl_env_freerun_begin: needs a batch of at most %d rows, "
-                    "a neighbourhood radius in (0, 1) voxel and a volume below 4 GiB", 64 * BLOCK);
+                    "a neighbourhood radius in (0, 1) voxel and a volume below 4 GiB", env->P.fuse_max_rows);
     hipStream_t s = (hipStream_t)hip_stream;
     env->fr_host_word = nullptr;
     if (host_counts) {

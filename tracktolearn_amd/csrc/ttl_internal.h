@@ -69,7 +69,11 @@ struct EnvParams {
     int xcd_remap;     // XCD-contiguous ranges of the processing order (TTL_XCD_REMAP)
     int xcd_rot;       // XCD x gathers range (x + xcd_rot) & 7 of the processing order
     int *counts;       // {n_continue, n_stopped}; 64 ints: the free-running step's words live here too
+    int fuse_max_rows; // largest batch of the one-launch step tail (TTL_FUSE_MAX_ROWS, <= TTL_FUSE_MAX_BLOCKS * 256)
 };
+
+// the one-launch tail scans at most this many per-block counts (one wave, four per lane)
+constexpr int TTL_FUSE_MAX_BLOCKS = 256;
 
 // free-running step (ttl_env_freerun_*): int offsets into EnvParams::counts of
 // {n_active, length, cur, steps done} -- live (between steps) and the snapshot

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
 
 // ---------------------------------------------------------------------------
 // k_prefix_state: the small-batch step tail in ONE launch (batches of at most
-// 64 * 256 streamlines without a processing order): what k_prefix and
+// P.fuse_max_rows <= 256 * 256 streamlines without a processing order): what k_prefix and
 // k_state_dd do in two.  Every workgroup scans the <= 64 per-block survivor
 // counts k_advance left (tracking_env.py:192-195 stable compaction), resolves
 // its own rows (continue_idx of the next step, row_dest, lengths of the
@@ -500,21 +500,32 @@ __device__ __forceinline__ void prefix_state_body(
     int *__restrict__ host_word, int seq, int cur) {
     constexpr int GPW = 64 / LPS;
     constexpr int ROWS = (BLOCK / 64) * GPW;
-    __shared__ int s_before[65];
+    // exclusive prefix over the <= TTL_FUSE_MAX_BLOCKS per-block survivor counts
+    // of k_advance: one wave, four counts per lane
+    __shared__ int s_before[TTL_FUSE_MAX_BLOCKS + 1];
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 64) {
-        const int c = lane < n_blocks ? P.block_counts[lane] : 0;
-        int v = c;
+        int c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            c[k] = 4 * lane + k < n_blocks ? P.block_counts[4 * lane + k] : 0;
+        const int local = (c[0] + c[1]) + (c[2] + c[3]);
+        int v = local;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(v, off);
             if (lane >= off) v += t;
         }
-        s_before[lane] = v - c;
-        if (lane == 63) s_before[64] = v;
+        int run = v - local;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s_before[4 * lane + k] = run;
+            run += c[k];
+        }
+        if (lane == 63) s_before[TTL_FUSE_MAX_BLOCKS] = v;
     }
     __syncthreads();
-    const int total = s_before[64];
+    const int total = s_before[TTL_FUSE_MAX_BLOCKS];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.counts[0] = total;
         P.counts[1] = n_active - total;
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_prefix_state_fr(
 bool ttl_detail_can_fuse_tail(const EnvParams &P, int n_active) {
     const int C4 = P.coef_pitch >> 2;
     const size_t vol_bytes = ttl_detail_sh_records(P) * P.coef_pitch * sizeof(float);
-    return n_active <= 64 * BLOCK && P.radius > 0.0f && P.radius < 1.0f &&
+    return n_active <= P.fuse_max_rows && P.radius > 0.0f && P.radius < 1.0f &&
            vol_bytes < (1ull << 32) && C4 <= 16 && P.n_coef >= 4;
 }
 

@@ -208,7 +208,7 @@ class TrackingEnvironment(BaseEnv):
         return state
 
     #: batches at least this large get a spatially sorted processing order
-    SPATIAL_ORDER_MIN = 16384
+    SPATIAL_ORDER_MIN = int(os.environ.get('TTL_FUSE_MAX_ROWS', '16384'))
 
     #: the order is rebuilt from the current positions every this many steps
     #: (a streamline crosses an 8-voxel brick in about ten 0.75-voxel steps;
@@ -519,7 +519,7 @@ class TrackingEnvironment(BaseEnv):
     # ------------------------------------------------------------------ #
     # free-running episode: policy + step in one HIP graph, no host in the loop
     #: largest batch the free-running step takes (the one-launch step tail)
-    FREERUN_MAX = 16384
+    FREERUN_MAX = int(os.environ.get('TTL_FUSE_MAX_ROWS', '16384'))
 
     def _has_action_noise(self):
         return False
