@@ -46,6 +46,13 @@ the rocprofv3 passes under profiles/ look at one workload at a time):
            every streamline tracked to exhaustion, then the finished tracts
            collated on rank 0 -- `collate_ms` INCLUDED in the end-to-end
            streamline-steps/s printed next to the step-only one.  -> `config4`.
+  pipelined  the headline batch as TWO half-batches of 131072 software-pipelined
+           on two HIP streams: the caller evaluates the policy per half, so the
+           latency-bound small kernels of one half (policy, advance, index
+           compaction) run under the state gather of the other.  Same streamlines,
+           same kernels, same results; only the schedule differs.  NOT the
+           headline (`value` stays the plain one-batch loop of the reference's
+           contract) -> `pipelined_halves`.
   hbm      the `roofline` object again in the regime where HBM binds: one
            GPU's shard of config 4 at N = 8 (131072 streamlines on the 145^3
            volume).  -> `roofline_hbm_regime` (rank 0's kernel times).
@@ -103,7 +110,7 @@ N_DIRS = WORKLOADS['c2']['n_dirs']
 MAX_LENGTH = WORKLOADS['c2']['max_length']
 #: rows of the HBM-regime roofline leg: one GPU's shard of config 4 at N = 8
 HBM_LEG_ROWS = 131072
-LEGS = ('weak', 'strong', 'config4', 'hbm')
+LEGS = ('weak', 'strong', 'config4', 'hbm', 'pipelined')
 
 
 def algorithmic_bytes(c, k):
@@ -402,6 +409,53 @@ def timed_windows(env, rows, steps, warmup, n_win, seed, grp):
     }
 
 
+def pipelined_windows(subject, device, seeds, parts, steps, warmup, n_win, seed, grp):
+    """`parts` envs over the same volumes, each with 1/parts of the seeds and a
+    HIP stream of its own, stepped alternately: windows of exactly `steps` steps
+    of EVERY part, bracketed like the headline's."""
+    import torch
+    rows = len(seeds) // parts
+    envs, streams = [], []
+    for k in range(parts):
+        env = make_env(subject, device, 'c2')
+        env.seeds = seeds[k * rows:(k + 1) * rows]
+        envs.append(env)
+        streams.append(torch.cuda.Stream())
+
+    def window(n_steps):
+        states = []
+        for env, s in zip(envs, streams):
+            with torch.cuda.stream(s):
+                states.append(env.reset(0, rows))
+        grp.barrier()
+        torch.cuda.synchronize()
+        total, t0 = 0, time.perf_counter()
+        for step in range(n_steps):
+            for k, (env, s) in enumerate(zip(envs, streams)):
+                with torch.cuda.stream(s):
+                    total += env._n_active
+                    env.step_device(env.scripted_actions(states[k], step, seed, WOBBLE))
+            for k, (env, s) in enumerate(zip(envs, streams)):
+                with torch.cuda.stream(s):
+                    states[k], _ = env.harvest()
+        torch.cuda.synchronize()
+        grp.barrier()
+        return total, time.perf_counter() - t0
+
+    window(max(warmup, 1))
+    times, units = [], 0
+    for _ in range(n_win):
+        units, dt = window(steps)
+        times.append(dt)
+    t_all = np.sort(grp.reduce(times, 'max'))
+    total_units = float(grp.reduce([units], 'sum')[0])
+    t_med = float(t_all[len(t_all) // 2])
+    return {'parts': parts, 'rows_per_part': rows, 'value': total_units / t_med,
+            'ms_per_step': t_med / steps * 1e3, 'streamline_steps': total_units,
+            'value_min': total_units / float(t_all[-1]),
+            'value_max': total_units / float(t_all[0]), 'windows': len(t_all)}
+
+
 def kernel_breakdown(env, rows, steps, seed):
     """Untimed replay of a window with every kernel class bracketed (the timed
     windows only bracket the dominant kernel, to keep the event records out of
@@ -575,7 +629,7 @@ def main(argv=None):
     if world != args.gpus:
         sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
-    need_c2 = bool(legs & {'weak', 'strong'})
+    need_c2 = bool(legs & {'weak', 'strong', 'pipelined'})
     need_c4 = bool(legs & {'config4', 'hbm'})
     subject = make_subject('c2') if need_c2 or not args.no_cpu_baseline else None
     cpu = None
@@ -645,6 +699,11 @@ def main(argv=None):
                             getattr(env, '_placement_search', None))
         del env
         torch.cuda.empty_cache()
+        if 'pipelined' in legs:
+            out['pipelined'] = pipelined_windows(
+                subject, device, synthetic_seeds(mask_c2, N_ACTOR, seed=100 + rank), 2,
+                args.steps, args.warmup, n_win, seed, grp)
+            torch.cuda.empty_cache()
 
     # ======================= 145^3 volume: config 4 + HBM regime ===========
     if need_c4:
@@ -765,6 +824,14 @@ def main(argv=None):
                 'windows': s['windows']['n'],
                 'same_run_as_value': bool(s.get('same_run_as_value', False)),
             }
+        if 'pipelined' in out:
+            pl = out['pipelined']
+            line['pipelined_halves'] = dict(
+                pl, what='the same 262144 streamlines per GPU as two half-batches, each with '
+                         'its own env handle and HIP stream, stepped alternately (policy per '
+                         'half): the small kernels of one half run under the gather of the '
+                         'other; not the headline loop',
+                vs_value=(pl['value'] / weak['value']) if weak else None)
         if 'config4' in out:
             c4 = out['config4']
             line['config4'] = {
@@ -797,6 +864,8 @@ def main(argv=None):
             line['placement_candidates_ms'] = tuned
         if search:
             line['placement_search'] = search
+        if out.get('c4_placement', (None, None))[0]:
+            line['placement_candidates_ms_config4'] = out['c4_placement'][0]
         if out.get('c4_placement', (None, None))[1]:
             line['placement_search_config4'] = out['c4_placement'][1]
         if not args.no_cpu_baseline:

@@ -1,13 +1,30 @@
 #!/usr/bin/env python3
-"""One-line digest of a bench.py JSON line: python benchmarks/show_bench.py <file>"""
+"""Digest of a bench.py JSON line: python benchmarks/show_bench.py <file>"""
 import json
 import sys
 
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-w, r = j['windows'], j['roofline']
-ep = j.get('whole_episode') or {}
-print(f"value {j['value'] / 1e6:.1f} M (min {w['value_min'] / 1e6:.1f}, max {w['value_max'] / 1e6:.1f}; "
-      f"with events {((w.get('value_median_with_events') or 0) / 1e6):.1f}, "
-      f"without {((w.get('value_median_without_events') or 0) / 1e6):.1f}) "
-      f"k_state {r['avg_launch_ms']:.4f} ms x{r['launches']} frac {r['frac']} "
-      f"whole episode {ep.get('streamline_steps_per_s_rank0', 0) / 1e6:.1f} M")
+if j.get('windows') and j.get('roofline'):
+    w, r = j['windows'], j['roofline']
+    ep = j.get('whole_episode') or {}
+    print(f"value {j['value'] / 1e6:.1f} M (min {w['value_min'] / 1e6:.1f}, max {w['value_max'] / 1e6:.1f}; "
+          f"with events {((w.get('value_median_with_events') or 0) / 1e6):.1f}, "
+          f"without {((w.get('value_median_without_events') or 0) / 1e6):.1f}) "
+          f"k_state {r['avg_launch_ms']:.4f} ms x{r['launches']} frac {r['frac']} "
+          f"other {r.get('other_kernels_ms_per_step')} "
+          f"whole episode {ep.get('streamline_steps_per_s_rank0', 0) / 1e6:.1f} M")
+if j.get('strong'):
+    s = j['strong']
+    print(f"strong: {s['value'] / 1e6:.1f} M at {s['n_actor_per_gpu']} per GPU (same run: {s['same_run_as_value']})")
+if j.get('pipelined_halves'):
+    p = j['pipelined_halves']
+    print(f"pipelined halves: {p['value'] / 1e6:.1f} M ({p['ms_per_step']:.4f} ms/step, x{p.get('vs_value') or 0:.3f} of value)")
+if j.get('config4'):
+    c = j['config4']
+    e = c['end_to_end']
+    print(f"config4: step-only {c['step_only']['value'] / 1e6:.1f} M; end to end {e['value_end_to_end'] / 1e6:.1f} M "
+          f"(track {e['track_ms']:.1f} ms + collate {e['collate_ms']:.1f} ms), track only {e['value_step_only'] / 1e6:.1f} M")
+if j.get('roofline_hbm_regime'):
+    r = j['roofline_hbm_regime']
+    print(f"hbm regime: k_state {r['avg_launch_ms']:.4f} ms, {r['units_per_launch']:.0f} units, frac {r['frac']}, "
+          f"shard {r.get('value_rank0_shard', 0) / 1e6:.1f} M")

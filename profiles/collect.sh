@@ -1,35 +1,41 @@
 #!/bin/bash
 # The judged profile set, from one box and one invocation:
-#   gpurun --timeout 900 -- 'bash profiles/collect.sh r01'
-# (profiled passes run `bench.py --no-cpu-baseline --no-whole-episode`: the same timed
-#  windows, without the forked CPU workers and without the episode-to-exhaustion tail whose
-#  small launches would dilute the per-kernel averages)
-# 1. bench.py alone            -> profiles/<tag>_bench.json
-# 2. rocprofv3 --kernel-trace --stats of the same command
-#                               -> profiles/<tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json
-# 3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; TCC has 4 slots)
-#                               -> profiles/<tag>_pmc_traffic.txt, pmc_traffic.json
-# 4. bench.py again with the fresh pmc_traffic.json (roofline.achieved / frac filled;
-#    the line carries the whole-episode figure too)
+#   gpurun --timeout 1100 -- 'bash profiles/collect.sh r03'
+# Profiled passes run ONE leg of bench.py at a time (`--legs`, the same timed
+# windows; without the forked CPU workers and without the episode-to-exhaustion
+# tail whose small launches would dilute the per-kernel averages):
+#   headline leg  bench.py --no-cpu-baseline --no-whole-episode --legs weak
+#   HBM regime    bench.py --no-cpu-baseline --no-whole-episode --legs hbm   (145^3 volume, 131072 rows)
+# per leg:
+# 1. rocprofv3 --kernel-trace --stats        -> profiles/<tag>[_c4shard]_kernel_stats.csv,
+#                                               <tag>[_c4shard]_bench_under_rocprof.json
+# 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; TCC has 4 slots)
+#                                             -> profiles/<tag>[_c4shard]_pmc_traffic.txt,
+#                                                pmc_traffic.json / pmc_traffic_c4shard.json
+# then 3. python3 bench.py (every leg, fresh pmc json files: roofline.achieved / frac filled)
+#                                             -> profiles/<tag>_bench.json
 # Results are copied under gpurun_out/profiles_<tag>/ (the only path that
 # travels back); copy them into profiles/ afterwards.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/prof_$tag
-mkdir -p $O
-T="timeout -k 10 400"
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/stats.json 2> $O/stats.log
-cp $O/stats.json $O/bench_under_rocprof.json
-$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/fetch.json 2> $O/fetch.log
-$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --no-cpu-baseline --no-whole-episode > $O/write.json 2> $O/write.log
-python3 profiles/pmc_summary.py $tag $O/stats $O/fetch $O/write
-$T python3 bench.py > $O/bench.json
 R=gpurun_out/profiles_$tag
-mkdir -p $R
-cp profiles/${tag}_kernel_stats.csv profiles/${tag}_pmc_traffic.txt profiles/pmc_traffic.json $R/
+mkdir -p $O $R
+T="timeout -k 10 400"
+for leg in weak hbm; do
+  sfx=""; js=pmc_traffic.json
+  if [ $leg = hbm ]; then sfx="_c4shard"; js=pmc_traffic_c4shard.json; fi
+  B="python3 bench.py --no-cpu-baseline --no-whole-episode --legs $leg"
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$sfx -- $B > $O/stats$sfx.json 2> $O/stats$sfx.log
+  $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch$sfx -- $B > $O/fetch$sfx.json 2> $O/fetch$sfx.log
+  $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write$sfx -- $B > $O/write$sfx.json 2> $O/write$sfx.log
+  python3 profiles/pmc_summary.py ${tag}$sfx $O/stats$sfx $O/fetch$sfx $O/write$sfx $js
+  cp $O/stats$sfx.json $R/${tag}${sfx}_bench_under_rocprof.json
+  cp profiles/${tag}${sfx}_kernel_stats.csv profiles/${tag}${sfx}_pmc_traffic.txt profiles/$js $R/
+  rm -rf $O/stats$sfx $O/fetch$sfx $O/write$sfx
+done
+$T python3 bench.py > $O/bench.json
 cp $O/bench.json $R/${tag}_bench.json
-cp $O/bench_under_rocprof.json $R/${tag}_bench_under_rocprof.json
-rm -rf $O/stats $O/fetch $O/write
-cut -c1-600 $R/${tag}_bench.json
+python3 benchmarks/show_bench.py $R/${tag}_bench.json

@@ -43,7 +43,8 @@ def search_launches(dirname):
     averages: many of them rewrite one buffer, which keeps its rows in the caches."""
     try:
         line = json.loads(open(dirname.rstrip('/') + '.json').read().strip().splitlines()[-1])
-        return 5 * sum(len(row) for row in line.get('placement_candidates_ms') or [])
+        tried = line.get('placement_candidates_ms') or line.get('placement_candidates_ms_config4')
+        return 5 * sum(len(row) for row in tried or [])
     except (OSError, ValueError, IndexError):
         return 0
 
