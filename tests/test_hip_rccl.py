@@ -101,3 +101,28 @@ def test_collate_and_gradient_exchange_on_a_world_size_1_nccl_group():
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert 'rccl-ok' in out.stdout
+
+
+def test_pack_streamlines_kernel_equals_the_masked_indexing():
+    """`ttl_pack_streamlines` (ABI v8; `parallel.pack_points` on CUDA tensors,
+    `get_streamlines`): the ragged pack of tracked streamlines, bit for bit what
+    boolean-mask indexing of the history gives, incl. rows that keep nothing and
+    a non-contiguous slice of the history buffer."""
+    import torch
+    from tracktolearn_amd import parallel
+    torch.manual_seed(1)
+    for n, T in ((1, 5), (257, 33), (5000, 268)):
+        hist = torch.randn((n, T + 2, 3), device='cuda:0')[:, :T]   # rows further apart than T points
+        keep = torch.randint(0, T + 1, (n,), device='cuda:0')
+        keep[0] = 0 if n > 1 else T
+        got = parallel.pack_points(hist, keep)
+        steps = torch.arange(T, device='cuda:0')
+        want = hist[steps[None, :] < keep[:, None]]
+        assert got.shape == want.shape and torch.equal(got, want)
+    empty = parallel.pack_points(torch.randn((4, 6, 3), device='cuda:0'),
+                                 torch.zeros(4, dtype=torch.int64, device='cuda:0'))
+    assert empty.shape == (0, 3)
+    # host tensors (the gloo tests) keep the indexing path
+    h = torch.randn(7, 5, 3)
+    k = torch.tensor([5, 0, 3, 1, 5, 2, 4])
+    assert parallel.pack_points(h, k).shape == (int(k.sum()), 3)

@@ -55,7 +55,9 @@ def pack_points(history, keep_len):
     total = int(ends[-1].item()) if n else 0
     out = torch.empty((total, 3), dtype=torch.float32, device=history.device)
     if total:
-        hist = history if history.is_contiguous() else history.contiguous()
+        # rows may be further apart than their points (a slice of a larger buffer)
+        hist = history if history.stride(2) == 1 and history.stride(1) == 3 \
+            else history.contiguous()
         offsets = ends - keep
         import ctypes as C
         _lib.check(_lib.load().ttl_pack_streamlines(
