@@ -459,16 +459,31 @@ def pipelined_windows(subject, device, seeds, parts, steps, warmup, n_win, seed,
 def kernel_breakdown(env, rows, steps, seed):
     """Untimed replay of a window with every kernel class bracketed (the timed
     windows only bracket the dominant kernel, to keep the event records out of
-    the other launch gaps): average ms per step of the other kernels."""
+    the other launch gaps): average ms per step of the other kernels -- the
+    step's own (advance, prefix, proc_scatter: library events) and the scripted
+    policy in front of it (torch events on the same stream)."""
     import torch
-    counter = {'state': env.reset(0, rows), 'step': 0, 'resets': 0}
+    state = env.reset(0, rows)
     classes = tuple(env.PROFILE_CLASSES)
     env.profile_begin(max_launches=max(16, steps + 8), classes=classes)
-    run_steps(env, steps, seed, counter, rows)
+    policy_ev = []
+    for step in range(steps):
+        if env._n_active == 0:
+            break
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        actions = env.scripted_actions(state, step, seed, WOBBLE)
+        e1.record()
+        policy_ev.append((e0, e1))
+        env.step_device(actions)
+        state, _ = env.harvest()
     torch.cuda.synchronize()
     prof = env.profile_end()
     n_steps = max(prof[classes[0]][1], 1)
-    return {k: prof[k][0] / n_steps for k in classes if k != 'state'}
+    out = {k: prof[k][0] / n_steps for k in classes if k != 'state'}
+    out['scripted_policy'] = sum(a.elapsed_time(b) for a, b in policy_ev) / max(len(policy_ev), 1)
+    out['sum'] = sum(out.values())
+    return out
 
 
 def track_to_exhaustion(env, state, seed, free_tail):
@@ -733,6 +748,11 @@ def main(argv=None):
             # one whole tractogram end to end: track every streamline to
             # exhaustion, then collate on rank 0 -- timed as one region
             warm = whole_episode(env4, rows4, seed, free_tail, grp)
+            # ... and one untimed collate of that warm-up tractogram, like the W
+            # warm-up steps: the first call pays for loading the code objects of
+            # the pack / index kernels (about 0.2 s at N = 1) and, with N > 1,
+            # for RCCL setting up its point-to-point connections
+            first_ms, _, _ = collate(env4, grp)
             grp.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -751,6 +771,7 @@ def main(argv=None):
                         'over ranks',
                 'streamline_steps': units, 'episode_steps_rank0': ep_steps,
                 'track_ms': t_track_max * 1e3, 'collate_ms': c_ms,
+                'collate_first_call_ms': first_ms,
                 'collate_bytes_to_root': c_bytes, 'end_to_end_ms': t_total_max * 1e3,
                 'value_step_only': units / t_track_max,
                 'value_end_to_end': units / t_total_max,

@@ -41,7 +41,7 @@ extern "C" {
 #define TTL_API
 #endif
 
-#define TTL_ABI_VERSION 8
+#define TTL_ABI_VERSION 9
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -352,12 +352,14 @@ TTL_API int ttl_env_view(ttl_env *env, const int32_t **continue_idx,
 /* Measurement support (bench.py): while profiling is on, every kernel launched
  * by ttl_env_step() is bracketed by HIP events on the caller's stream.
  * ttl_env_profile_end() synchronises those events and returns, per kernel
- * class {0: advance, 1: prefix, 2: state gather}, the summed duration in ms
- * and the number of launches, then switches profiling off. */
+ * class {0: advance, 1: prefix, 2: state gather, 3: processing-order
+ * compaction (ABI v9)}, the summed duration in ms and the number of launches,
+ * then switches profiling off. */
+#define TTL_PROFILE_CLASSES 4
 TTL_API int ttl_env_profile_begin(ttl_env *env, int32_t max_launches,
                           int32_t class_mask /* bit k = time class k */);
-TTL_API int ttl_env_profile_end(ttl_env *env, double *total_ms /*[3]*/,
-                        int32_t *n_launches /*[3]*/);
+TTL_API int ttl_env_profile_end(ttl_env *env, double *total_ms /*[TTL_PROFILE_CLASSES]*/,
+                        int32_t *n_launches /*[TTL_PROFILE_CLASSES]*/);
 
 /* Scripted, policy-free actions for "env.step only" runs (stands in
  * for agent.select_action, TTL/algorithms/rl.py:91): step 0 -> a random

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (keep above the CDLL below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 SH_LINEAR, SH_BRICK4 = 0, 1
 MODE_F32 = 0
 MODE_F64DIR = 1

@@ -928,8 +928,8 @@ struct ttl_env {
     int prof_on;
     int prof_mask;    // bit k: time kernel class k
     int prof_cap;     // event pairs available per kernel class
-    int prof_n[3];    // launches recorded: advance, prefix, state
-    hipEvent_t *prof_ev[3];  // [2 * prof_cap] start/stop pairs
+    int prof_n[TTL_PROFILE_CLASSES];    // launches recorded: advance, prefix, state, proc_scatter
+    hipEvent_t *prof_ev[TTL_PROFILE_CLASSES];  // [2 * prof_cap] start/stop pairs
 };
 
 static void prof_mark(ttl_env *e, int which, int stop, hipStream_t s) {
@@ -1250,10 +1250,10 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->n_exact = 0;
     e->fr_cap = 0;
     e->fr_host_word = nullptr;
-    e->prof_mask = 7;
+    e->prof_mask = (1 << TTL_PROFILE_CLASSES) - 1;
     e->prof_on = 0;
     e->prof_cap = 0;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < TTL_PROFILE_CLASSES; ++k) {
         e->prof_n[k] = 0;
         e->prof_ev[k] = nullptr;
     }
@@ -1262,7 +1262,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
 }
 
 static void prof_free(ttl_env *env) {
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < TTL_PROFILE_CLASSES; ++k) {
         if (env->prof_ev[k]) {
             for (int j = 0; j < 2 * env->prof_cap; ++j) (void)hipEventDestroy(env->prof_ev[k][j]);
             delete[] env->prof_ev[k];
@@ -1284,11 +1284,12 @@ void ttl_env_destroy(ttl_env *env) {
 }
 
 int ttl_env_profile_begin(ttl_env *env, int32_t max_launches, int32_t class_mask) {
-    if (!env || max_launches < 1 || max_launches > (1 << 20) || !(class_mask & 7))
+    const int all = (1 << TTL_PROFILE_CLASSES) - 1;
+    if (!env || max_launches < 1 || max_launches > (1 << 20) || !(class_mask & all))
         return fail(TTL_ERR_INVALID, "ttl_env_profile_begin: bad arguments");
     prof_free(env);
-    env->prof_mask = class_mask & 7;
-    for (int k = 0; k < 3; ++k) {
+    env->prof_mask = class_mask & all;
+    for (int k = 0; k < TTL_PROFILE_CLASSES; ++k) {
         env->prof_ev[k] = new (std::nothrow) hipEvent_t[2 * (size_t)max_launches];
         if (!env->prof_ev[k]) return fail(TTL_ERR_INVALID, "ttl_env_profile_begin: out of host memory");
         for (int j = 0; j < 2 * max_launches; ++j) HIP_TRY(hipEventCreate(&env->prof_ev[k][j]));
@@ -1302,7 +1303,7 @@ int ttl_env_profile_end(ttl_env *env, double *total_ms, int32_t *n_launches) {
     if (!env || !total_ms || !n_launches)
         return fail(TTL_ERR_INVALID, "ttl_env_profile_end: null argument");
     if (!env->prof_cap) return fail(TTL_ERR_STATE, "ttl_env_profile_end: profiling is off");
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < TTL_PROFILE_CLASSES; ++k) {
         double acc = 0.0;
         for (int j = 0; j < env->prof_n[k]; ++j) {
             float ms = 0.f;
@@ -1517,9 +1518,11 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         // next step's processing order: this one, compacted in its own order
         // (ranks from k_prefix) and renumbered with the survivors' new row
         // ids; plus this step's per-slot records for the gather
+        prof_mark(env, 3, 0, s);
         hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, proc,
                            env->proc[env->proc_cur ^ 1], n_active, nb,
                            env->local_sort && env->P.slot_rec);
+        prof_mark(env, 3, 1, s);
         HIP_TRY(hipGetLastError());
     }
     prof_mark(env, 2, 0, s);

@@ -765,24 +765,24 @@ class TrackingEnvironment(BaseEnv):
         return out
 
     #: kernel classes `profile_begin` can bracket (ttl_env_profile_begin's mask bits)
-    PROFILE_CLASSES = ('advance', 'prefix', 'state')
+    PROFILE_CLASSES = ('advance', 'prefix', 'state', 'proc_scatter')
 
     def profile_begin(self, max_launches=4096, classes=('state',)):
-        """Bracket the step kernels of the given classes ('advance', 'prefix',
-        'state') with HIP events on the launch stream."""
-        mask = sum(1 << ('advance', 'prefix', 'state').index(c) for c in classes)
+        """Bracket the step kernels of the given classes (PROFILE_CLASSES) with
+        HIP events on the launch stream."""
+        mask = sum(1 << self.PROFILE_CLASSES.index(c) for c in classes)
         _lib.check(self._lib.ttl_env_profile_begin(self._handle, max_launches,
                                                    mask), 'ttl_env_profile_begin')
 
     def profile_end(self):
-        """{'advance'|'prefix'|'state': (total_ms, n_launches)}."""
+        """{class: (total_ms, n_launches)} for every class of PROFILE_CLASSES."""
         import ctypes as C
-        ms = (C.c_double * 3)()
-        n = (C.c_int32 * 3)()
+        k = len(self.PROFILE_CLASSES)
+        ms = (C.c_double * k)()
+        n = (C.c_int32 * k)()
         _lib.check(self._lib.ttl_env_profile_end(self._handle, ms, n),
                    'ttl_env_profile_end')
-        return {k: (ms[i], n[i]) for i, k in
-                enumerate(('advance', 'prefix', 'state'))}
+        return {c: (ms[i], n[i]) for i, c in enumerate(self.PROFILE_CLASSES)}
 
     # ------------------------------------------------------------------ #
     # host views of the per-streamline state (reference attribute names)
