@@ -47,6 +47,11 @@ def one(rng, k):
     os.environ['TTL_ORDER_SORT'] = str(knobs.choice([0, 1]))
     os.environ['TTL_STORE_FLAVOUR'] = str(knobs.choice([0, 8]))      # tail-merge variants
     os.environ['TTL_XCD_ROTATE'] = str(knobs.randint(8))
+    # round-3 knobs (again a generator of their own): largest batch of the
+    # one-launch step tail, step() handing out lazily gathered state rows
+    knobs3 = np.random.RandomState(3000 + k)
+    os.environ['TTL_FUSE_MAX_ROWS'] = str(knobs3.choice([4096, 16384, 65536]))
+    TrackingEnvironment.lazy_step_state = bool(knobs3.randint(2))
     X, Y, Z = shape
     sh = (0.1 * rng.standard_normal((X, Y, Z, C))).astype(np.float32)
     g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing='ij'))
