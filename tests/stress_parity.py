@@ -50,7 +50,9 @@ def one(rng, k):
     # round-3 knobs (again a generator of their own): largest batch of the
     # one-launch step tail, step() handing out lazily gathered state rows
     knobs3 = np.random.RandomState(3000 + k)
-    os.environ['TTL_FUSE_MAX_ROWS'] = str(knobs3.choice([4096, 16384, 65536]))
+    fuse_max = int(knobs3.choice([4096, 16384, 65536]))
+    os.environ['TTL_FUSE_MAX_ROWS'] = str(fuse_max)        # read when the handle is created ...
+    TrackingEnvironment.FREERUN_MAX = fuse_max              # ... and by the host class at import
     TrackingEnvironment.lazy_step_state = bool(knobs3.randint(2))
     X, Y, Z = shape
     sh = (0.1 * rng.standard_normal((X, Y, Z, C))).astype(np.float32)
