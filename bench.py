@@ -53,6 +53,13 @@ the rocprofv3 passes under profiles/ look at one workload at a time):
            same kernels, same results; only the schedule differs.  NOT the
            headline (`value` stays the plain one-batch loop of the reference's
            contract) -> `pipelined_halves`.
+  shapes   (N = 1 only) the other BASELINE shapes through the same loop, three
+           windows each, so that they are driver-timed too: config 2 at K = 100
+           (the shipped model's state width), config 3's env side (65536,
+           reward on), config 1's shape (32^3, 4096, K = 100, float64
+           directions) and config 2 through the reference's OWN calling contract
+           (`env.step(numpy)` -> host reward / dones -> `harvest()`, PCIe
+           inclusive; never `value`).  -> `other_shapes`.
   hbm      the `roofline` object again in the regime where HBM binds: one
            GPU's shard of config 4 at N = 8 (131072 streamlines on the 145^3
            volume).  -> `roofline_hbm_regime` (rank 0's kernel times).
@@ -110,7 +117,7 @@ N_DIRS = WORKLOADS['c2']['n_dirs']
 MAX_LENGTH = WORKLOADS['c2']['max_length']
 #: rows of the HBM-regime roofline leg: one GPU's shard of config 4 at N = 8
 HBM_LEG_ROWS = 131072
-LEGS = ('weak', 'strong', 'config4', 'hbm', 'pipelined')
+LEGS = ('weak', 'strong', 'config4', 'hbm', 'pipelined', 'shapes')
 
 
 def algorithmic_bytes(c, k):
@@ -135,10 +142,27 @@ def compulsory_bytes(c, k, n_mask_voxels, units_per_launch):
     return row + per_streamline + n_mask_voxels * record / max(units_per_launch, 1.0)
 
 
+#: leg `shapes`: the other BASELINE shapes (same loop; `host`: the reference's
+#: own calling contract instead of the device-resident loop)
+OTHER_SHAPES = {
+    'c2_K100': dict(D=96, n_total=262144, n_dirs=100, noisy=False, max_length=200.0,
+                    what='config 2 at n_dirs=100 (state width 615, the shipped model\'s)'),
+    'c3_env': dict(D=96, n_total=65536, n_dirs=4, noisy=False, max_length=200.0, reward=True,
+                   what='config 3, env side: 65536 streamlines, alignment reward on'),
+    'c1_shape': dict(D=32, n_total=4096, n_dirs=100, noisy=True, max_length=300.0,
+                     what='config 1\'s shape: 32^3, 4096 streamlines, n_dirs=100, float64 '
+                          'directions'),
+    'c2_host_contract': dict(D=96, n_total=262144, n_dirs=4, noisy=False, max_length=200.0,
+                             host=True,
+                             what='config 2 through env.step(numpy actions) -> host reward / '
+                                  'dones -> env.harvest() (rl.py:93-102), PCIe inclusive'),
+}
+
+
 def make_subject(workload='c2'):
     from tracktolearn_amd.utils.synthetic import synthetic_subject
-    w = WORKLOADS[workload]
-    return synthetic_subject(w['D'], C, seed=1234, peaks=False,
+    w = WORKLOADS.get(workload) or OTHER_SHAPES[workload]
+    return synthetic_subject(w['D'], C, seed=1234, peaks=bool(w.get('reward')),
                              affine_dtype=np.float64 if w['noisy'] else np.float32)
 
 
@@ -147,10 +171,10 @@ def make_env(subject, device, workload='c2'):
     import torch
     from tracktolearn_amd.environments import (NoisyTrackingEnvironment,
                                                TrackingEnvironment)
-    w = WORKLOADS[workload]
+    w = WORKLOADS.get(workload) or OTHER_SHAPES[workload]
     dto = dict(n_dirs=w['n_dirs'], theta=THETA, npv=1, binary_stopping_threshold=0.1,
                step_size=STEP_MM, min_length=20.0, max_length=w['max_length'],
-               compute_reward=False, alignment_weighting=1.0, oracle_bonus=0.0,
+               compute_reward=bool(w.get('reward')), alignment_weighting=1.0, oracle_bonus=0.0,
                rng=np.random.RandomState(0), device=torch.device(device),
                target_sh_order=8, noise=0.0, fa_map=None)
     cls = NoisyTrackingEnvironment if w['noisy'] else TrackingEnvironment
@@ -167,8 +191,10 @@ def shard_seeds(mask_data, n_total, rank, world, seed=100):
     return seeds[lo:hi]
 
 
-def run_steps(env, n_steps, seed, counter, rows):
-    """n_steps passes of the hot path; returns streamline-steps processed."""
+def run_steps(env, n_steps, seed, counter, rows, host_contract=False):
+    """n_steps passes of the hot path; returns streamline-steps processed.
+    `host_contract`: the reference's own calling sequence (rl.py:93-102): the
+    action batch goes to the host and into `env.step` as a numpy array."""
     state = counter['state']
     total = 0
     for _ in range(n_steps):
@@ -178,7 +204,10 @@ def run_steps(env, n_steps, seed, counter, rows):
             counter['resets'] += 1
         n = env._n_active
         actions = env.scripted_actions(state, counter['step'], seed, WOBBLE)
-        env.step_device(actions)
+        if host_contract:
+            env.step(actions.to(device='cpu', copy=True).numpy())
+        else:
+            env.step_device(actions)
         state, _ = env.harvest()
         total += n
         counter['step'] += 1
@@ -346,14 +375,14 @@ class Dist:
         return t.cpu().numpy()
 
 
-def timed_windows(env, rows, steps, warmup, n_win, seed, grp):
+def timed_windows(env, rows, steps, warmup, n_win, seed, grp, host_contract=False):
     """`warmup` untimed steps, then `n_win` windows of exactly `steps` steps,
     each from a fresh untimed reset and bracketed by barrier + synchronize.
     Returns a dict: per-window wall times (max over ranks), streamline-steps of
     one window (sum over ranks), the dominant kernel's event time on THIS rank."""
     import torch
     counter = {'state': env.reset(0, rows), 'step': 0, 'resets': 0}
-    run_steps(env, warmup, seed, counter, rows)
+    run_steps(env, warmup, seed, counter, rows, host_contract)
     # exercise the periodic re-sort of the processing order once outside the
     # timed regions
     if env._n_active:
@@ -373,7 +402,7 @@ def timed_windows(env, rows, steps, warmup, n_win, seed, grp):
         grp.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n_units = run_steps(env, steps, seed, counter, rows)
+        n_units = run_steps(env, steps, seed, counter, rows, host_contract)
         torch.cuda.synchronize()
         grp.barrier()
         times.append(time.perf_counter() - t0)
@@ -720,6 +749,29 @@ def main(argv=None):
                 args.steps, args.warmup, n_win, seed, grp)
             torch.cuda.empty_cache()
 
+    # ======================= the other BASELINE shapes (N = 1) =============
+    if 'shapes' in legs and world == 1:
+        from tracktolearn_amd.utils.synthetic import synthetic_seeds
+        shapes = {}
+        for name, w in OTHER_SHAPES.items():
+            subj = subject if (subject is not None and w['D'] == D and not w.get('reward')
+                               and not w['noisy']) else make_subject(name)
+            env_s = make_env(subj, device, name)
+            env_s.seeds = synthetic_seeds(subj[1].data, w['n_total'], seed=100)
+            r = timed_windows(env_s, w['n_total'], args.steps, args.warmup, 3, seed, grp,
+                              host_contract=bool(w.get('host')))
+            shapes[name] = {
+                'what': w['what'], 'volume': [w['D']] * 3 + [C], 'n_actor': w['n_total'],
+                'n_dirs': w['n_dirs'],
+                'loop': 'step(numpy) + harvest' if w.get('host') else 'step_device + harvest',
+                'value': r['value'], 'ms_per_step': r['ms_per_step'],
+                'value_min': r['windows']['value_min'], 'value_max': r['windows']['value_max'],
+                'k_state_ms': r['state_ms'] / max(r['state_n'], 1), 'windows': 3,
+            }
+            del env_s
+            torch.cuda.empty_cache()
+        out['shapes'] = shapes
+
     # ======================= 145^3 volume: config 4 + HBM regime ===========
     if need_c4:
         from tracktolearn_amd.utils.synthetic import synthetic_seeds
@@ -853,6 +905,10 @@ def main(argv=None):
                          'half): the small kernels of one half run under the gather of the '
                          'other; not the headline loop',
                 vs_value=(pl['value'] / weak['value']) if weak else None)
+        if 'shapes' in out:
+            line['other_shapes'] = out['shapes']
+        elif 'shapes' in legs and world > 1:
+            line['other_shapes'] = 'N=1 only'
         if 'config4' in out:
             c4 = out['config4']
             line['config4'] = {

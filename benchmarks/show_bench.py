@@ -28,3 +28,6 @@ if j.get('roofline_hbm_regime'):
     r = j['roofline_hbm_regime']
     print(f"hbm regime: k_state {r['avg_launch_ms']:.4f} ms, {r['units_per_launch']:.0f} units, frac {r['frac']}, "
           f"shard {r.get('value_rank0_shard', 0) / 1e6:.1f} M")
+if isinstance(j.get('other_shapes'), dict):
+    for name, o in j['other_shapes'].items():
+        print(f"{name}: {o['value'] / 1e6:.1f} M ({o['ms_per_step'] * 1e3:.1f} us/step, k_state {o['k_state_ms']:.4f} ms; {o['loop']})")

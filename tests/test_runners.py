@@ -414,3 +414,25 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert e2e['streamline_steps'] > 262144 * 10
     assert line['roofline_hbm_regime']['units_per_launch'] > 100000
     assert line['cpu_baseline'].startswith('N=1 only') if 'cpu_baseline' in line else True
+    assert e2e['collate_first_call_ms'] > 0         # the untimed warm-up collate
+    assert line['other_shapes'] == 'N=1 only'       # the `shapes` leg is a one-GPU leg
+
+
+@pytest.mark.gpu
+def test_bench_other_shapes_leg():
+    """`bench.py --legs shapes`: the other BASELINE shapes in the line (one GPU),
+    the reference's own calling contract among them."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--legs', 'shapes',
+                          '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _last_json_line(out.stdout)
+    shapes = line['other_shapes']
+    assert set(shapes) == {'c2_K100', 'c3_env', 'c1_shape', 'c2_host_contract'}
+    for name, o in shapes.items():
+        assert o['value'] > 0 and o['windows'] == 3, name
+    assert shapes['c2_K100']['n_dirs'] == 100 and shapes['c3_env']['n_actor'] == 65536
+    assert shapes['c2_host_contract']['loop'].startswith('step(numpy)')
+    # PCIe inclusive: slower than the device-resident loop on the same shape
+    assert shapes['c2_host_contract']['value'] < 1.3e9
