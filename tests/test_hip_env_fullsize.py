@@ -257,6 +257,7 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
     spans = [(m.ptr, m.ptr + m.nbytes) for m in env_t._state_ring_memory]
 
     def in_ring(t):
+        t = getattr(t, '_rows', t)          # step() hands out lazily gathered rows
         return any(lo <= t.data_ptr() < hi for lo, hi in spans)
     st = env_t.reset(0, N)
     held, copies = [st], [st.cpu().numpy()]
@@ -267,11 +268,28 @@ def test_volume_placement_tuning_changes_no_result_and_draws_nothing(monkeypatch
         st, _ = env_t.harvest()
         held.append(st)
         copies.append(st.cpu().numpy())
-    # the tensors of the last three steps are intact (ring of four)
+    # every tensor the caller still holds is intact: a placed buffer is handed
+    # out again only when nothing refers to it (round 3)
+    assert not env_t.state_ring_rotates
     for got, want in zip(held, copies):
         assert np.array_equal(got.cpu().numpy(), want)
-    ns, _, _, _ = env_t.step(env_t.scripted_actions(st, 3, seed=3, wobble=0.05).cpu().numpy())
-    assert not in_ring(ns)                        # step() hands out fresh tensors
+    # ... all four buffers are held now, so the next step -- step(), the
+    # reference's contract, draws from the same pool -- gets a fresh allocation
+    assert all(in_ring(t) for t in held) and len({t.data_ptr() for t in held}) == 4
+    a_host = env_t.scripted_actions(st, 3, seed=3, wobble=0.05).cpu().numpy()
+    ns, _, _, _ = env_t.step(a_host)
+    assert not in_ring(ns)
+    st, _ = env_t.harvest()
+    for got, want in zip(held, copies):
+        assert np.array_equal(got.cpu().numpy(), want)
+    # ... and once the caller lets go, the placed buffers come back into use
+    del held[:], ns
+    a_host = env_t.scripted_actions(st, 4, seed=3, wobble=0.05).cpu().numpy()
+    ns, _, _, _ = env_t.step(a_host)
+    assert in_ring(ns)
+    st, _ = env_t.harvest()
+    assert in_ring(st)
+    del ns
     # a second large reset does not tune again
     env_t.reset(0, N)
     assert len(env_t._sh_tuned) == 3

@@ -397,6 +397,9 @@ class BaseEnv(object):
                 self._n_max = 0
                 row = []
                 for ri, (ring, rmem) in enumerate(candidates):
+                    # a candidate is a "ring" of one buffer that every step of the
+                    # probe must write, referenced or not
+                    self._state_ring_search = True
                     self._state_ring, self._state_ring_pos = ring, 0
                     state = self._start(seeds[:n])
                     self.profile_begin(16, classes=('state',))
@@ -419,6 +422,7 @@ class BaseEnv(object):
                 self._sh_tuned.append(row)
             self._placement_search.update(pairs_timed=len(timed), early_exit=settled)
         finally:
+            self._state_ring_search = False
             vi, ri = (best[1], best[2]) if best else (0, 0)
             self._sh_packed, self._sh_memory = vols[vi]
             self._state_ring, self._state_ring_memory = None, None
@@ -478,31 +482,61 @@ class BaseEnv(object):
         return torch.empty((n, self._state_pitch), dtype=torch.float32,
                            device=self.device)[:, :self._state_width]
 
-    #: state buffers of the device-resident loop (``step_device``) in memory
-    #: whose placement was measured: a ring of this many buffers, so that the
-    #: tensors of the last STATE_RING - 1 steps stay intact (TTL_STATE_RING=0:
-    #: a fresh ``torch.empty`` per step, as ``step()`` always does)
+    #: state rows of large batches live in memory whose placement was measured: a
+    #: pool of this many buffers (TTL_STATE_RING=0: a fresh ``torch.empty`` per
+    #: step).  A buffer is handed out again only when no tensor refers to it any
+    #: more (the use count of its storage), so every state tensor stays intact
+    #: for as long as the caller holds it, exactly like a fresh allocation; when
+    #: the caller holds them all, the step falls back to a fresh allocation.
     STATE_RING = 4
+    #: TTL_STATE_RING_ROTATE=1 (and a torch without the storage use count): the
+    #: round-2 behaviour, a plain ring -- a tensor is overwritten STATE_RING steps
+    #: after it was handed out, referenced or not, and ``step()`` allocates
+    STATE_RING_ROTATE = os.environ.get('TTL_STATE_RING_ROTATE', '0') == '1' or \
+        not hasattr(torch._C, '_storage_Use_Count')
 
     @property
     def state_ring_len(self):
-        """How many state tensors of the device-resident loop are alive at a time:
-        a tensor returned by ``reset`` / ``step_device`` / ``harvest`` stays intact
-        while at most ``state_ring_len - 1`` further state tensors are handed out,
-        then its buffer is reused.  0: every tensor is a fresh allocation (small
-        batches, ``TTL_STATE_RING=0``, and always ``step()``).  Callers that keep
-        states across steps (n-step buffers, trajectories) clone, or assert on
-        this."""
+        """Number of placed state buffers the env rotates through (0: none, every
+        state tensor is a fresh allocation).  With ``state_ring_rotates`` False
+        (the default) this is an implementation detail: buffers are only reused
+        once nothing refers to them.  With it True, a tensor returned by
+        ``reset`` / ``step_device`` / ``harvest`` is overwritten after
+        ``state_ring_len - 1`` further state tensors were handed out: clone what
+        must live longer."""
         return len(self._state_ring) if getattr(self, '_state_ring', None) else 0
 
+    @property
+    def state_ring_rotates(self):
+        return bool(self.state_ring_len) and (self.STATE_RING_ROTATE or
+                                              getattr(self, '_state_ring_search', False))
+
+    @staticmethod
+    def _storage_users(t):
+        # TensorImpls + Python storage objects alive on this storage (the probe's
+        # own temporary included, in the baseline as well)
+        return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
     def _ring_state(self, n):
-        """State rows for a reset / ``step_device``: the next buffer of the placed
-        ring when there is one that fits, a fresh tensor otherwise."""
+        """State rows for a reset / step of a large batch: a placed buffer that
+        nothing refers to any more when there is one that fits, a fresh tensor
+        otherwise."""
         ring = self._state_ring
         if ring is None or n > ring[0].shape[0]:
             return self._new_state(n)
-        self._state_ring_pos = (self._state_ring_pos + 1) % len(ring)
-        return ring[self._state_ring_pos][:n]
+        if self.STATE_RING_ROTATE or getattr(self, '_state_ring_search', False):
+            self._state_ring_pos = (self._state_ring_pos + 1) % len(ring)
+            return ring[self._state_ring_pos][:n]
+        if getattr(self, '_state_ring_idle_of', None) is not ring:
+            # first use of this pool: nothing has been handed out yet
+            self._state_ring_idle = [self._storage_users(b) for b in ring]
+            self._state_ring_idle_of = ring
+        for k in range(1, len(ring) + 1):
+            pos = (self._state_ring_pos + k) % len(ring)
+            if self._storage_users(ring[pos]) <= self._state_ring_idle[pos]:
+                self._state_ring_pos = pos
+                return ring[pos][:n]
+        return self._new_state(n)       # the caller still holds a tensor on every buffer
 
     def _stream(self):
         """Raw HIP stream torch currently launches on for this device (the

@@ -306,10 +306,12 @@ class TrackingEnvironment(BaseEnv):
         a = self._actions_to_device(actions)
         noise = self._noise_for(a)
         self._refresh_processing_order()
-        # the device-resident loop writes into the placed ring (env.py); step()
-        # hands out fresh tensors as the reference does
-        state = self._ring_state(n) if order == _lib.ORDER_PARTITION and not host_outputs \
-            else self._new_state(n)
+        # rows written survivors first land in a placed buffer that nothing refers
+        # to any more (env.py:_ring_state; with the round-2 plain ring, step() keeps
+        # allocating: its callers may hold states for any number of steps)
+        pooled = order == _lib.ORDER_PARTITION and \
+            not (host_outputs and self.state_ring_rotates)
+        state = self._ring_state(n) if pooled else self._new_state(n)
         done = torch.empty(n, dtype=torch.uint8, device=self.device)
         reward = None
         if self.compute_reward:
