@@ -60,6 +60,12 @@ the rocprofv3 passes under profiles/ look at one workload at a time):
            directions) and config 2 through the reference's OWN calling contract
            (`env.step(numpy)` -> host reward / dones -> `harvest()`, PCIe
            inclusive; never `value`).  -> `other_shapes`.
+  learner  (N = 1 only) BASELINE configs[2]: one SAC training step at
+           n_actor = 65536, hidden 1024-1024, batch 4096, float32 (policy
+           forward -> env step with the alignment reward -> replay add ->
+           sample -> SACAuto.update -> harvest), and the update alone.  The
+           GEMMs are PyTorch-ROCm's (hipBLASLt fp32 MFMA), the env step is
+           this library's.  -> `config3_training`.
   hbm      the `roofline` object again in the regime where HBM binds: one
            GPU's shard of config 4 at N = 8 (131072 streamlines on the 145^3
            volume).  -> `roofline_hbm_regime` (rank 0's kernel times).
@@ -117,7 +123,7 @@ N_DIRS = WORKLOADS['c2']['n_dirs']
 MAX_LENGTH = WORKLOADS['c2']['max_length']
 #: rows of the HBM-regime roofline leg: one GPU's shard of config 4 at N = 8
 HBM_LEG_ROWS = 131072
-LEGS = ('weak', 'strong', 'config4', 'hbm', 'pipelined', 'shapes')
+LEGS = ('weak', 'strong', 'config4', 'hbm', 'pipelined', 'shapes', 'learner')
 
 
 def algorithmic_bytes(c, k):
@@ -772,6 +778,18 @@ def main(argv=None):
             torch.cuda.empty_cache()
         out['shapes'] = shapes
 
+    # ======================= config 3: one SAC training step (N = 1) =======
+    if 'learner' in legs and world == 1:
+        from benchmarks.bench_learner import measure as learner_measure
+        out['learner'] = learner_measure(device=device)
+        torch.cuda.empty_cache()
+        # the same with SACAuto.update replayed from a HIP graph (enable_graph())
+        graphed = learner_measure(device=device, graph=True)
+        out['learner']['graphed_update'] = {k: graphed[k] for k in
+                                            ('update_ms', 'train_step_ms',
+                                             'train_streamline_steps_per_s')}
+        torch.cuda.empty_cache()
+
     # ======================= 145^3 volume: config 4 + HBM regime ===========
     if need_c4:
         from tracktolearn_amd.utils.synthetic import synthetic_seeds
@@ -905,6 +923,17 @@ def main(argv=None):
                          'half): the small kernels of one half run under the gather of the '
                          'other; not the headline loop',
                 vs_value=(pl['value'] / weak['value']) if weak else None)
+        if 'learner' in out:
+            line['config3_training'] = dict(
+                out['learner'],
+                what='BASELINE configs[2]: SAC (automatic entropy), hidden 1024-1024, '
+                     'n_actor=65536, batch 4096, 96^3x45 volume, n_dirs=4, alignment reward; '
+                     'train_step_ms = policy forward + env step + replay add + sample + '
+                     'update + harvest, 24 steps after 3 warm-up steps; update_ms = '
+                     'SACAuto.update alone; graphed_update = the same with the update '
+                     'replayed from a HIP graph; fp32')
+        elif 'learner' in legs and world > 1:
+            line['config3_training'] = 'N=1 only'
         if 'shapes' in out:
             line['other_shapes'] = out['shapes']
         elif 'shapes' in legs and world > 1:

@@ -28,18 +28,15 @@ def timeit(fn, n, warm=3):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--hidden', default='1024-1024')
-    ap.add_argument('--n_actor', type=int, default=65536)
-    ap.add_argument('--batch', type=int, default=4096)
-    ap.add_argument('--graph', action='store_true')
-    args = ap.parse_args()
+def measure(hidden='1024-1024', n_actor=65536, batch=4096, graph=False, device='cuda:0'):
+    """The timings as a dict (bench.py's `learner` leg calls this)."""
+    import argparse as _a
+    args = _a.Namespace(hidden=hidden, n_actor=n_actor, batch=batch, graph=graph)
     from tracktolearn_amd.algorithms.sac_auto import SACAuto
     from tracktolearn_amd.environments import TrackingEnvironment
     from tracktolearn_amd.utils.synthetic import (synthetic_seeds,
                                                   synthetic_subject)
-    dev = torch.device('cuda:0')
+    dev = torch.device(device)
     subject = synthetic_subject(96, 45, seed=1234, peaks=True)
     dto = dict(n_dirs=4, theta=30.0, npv=1, binary_stopping_threshold=0.1,
                step_size=0.75, min_length=20.0, max_length=200.0,
@@ -69,27 +66,42 @@ def main():
     out['sample_ms'] = timeit(lambda: alg.replay_buffer.sample(args.batch), 30)
     alg.start_timesteps = 0
     # full training steps on a fresh episode
-    state = env.reset(0, args.n_actor)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n_units = 0
-    steps = 12
-    for _ in range(steps):
-        if state.shape[0] == 0:          # a random policy ends episodes fast
-            state = env.reset(0, args.n_actor)
-        with torch.no_grad():
-            a = alg.sample_action(state)
-        n = a.shape[0]
-        ns, r, d, info = env.step_device(a)
-        alg.replay_buffer.add_partitioned(state, a, ns, info['row_dest'], r, d)
-        alg.update(alg.replay_buffer.sample(args.batch))
-        state, _ = env.harvest()
-        n_units += n
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def train_steps(steps):
+        state = env.reset(0, args.n_actor)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_units = 0
+        for _ in range(steps):
+            if state.shape[0] == 0:          # a random policy ends episodes fast
+                state = env.reset(0, args.n_actor)
+            with torch.no_grad():
+                a = alg.sample_action(state)
+            n = a.shape[0]
+            ns, r, d, info = env.step_device(a)
+            alg.replay_buffer.add_partitioned(state, a, ns, info['row_dest'], r, d)
+            alg.update(alg.replay_buffer.sample(args.batch))
+            state, _ = env.harvest()
+            n_units += n
+        torch.cuda.synchronize()
+        return n_units, time.perf_counter() - t0
+    train_steps(3)                           # warm-up (first-call costs, graph capture)
+    steps = 24
+    n_units, dt = train_steps(steps)
+    out['train_steps'] = steps
     out['train_step_ms'] = dt / steps * 1e3
+    out['train_rows_per_step'] = n_units / steps
     out['train_streamline_steps_per_s'] = n_units / dt
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--hidden', default='1024-1024')
+    ap.add_argument('--n_actor', type=int, default=65536)
+    ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--graph', action='store_true')
+    args = ap.parse_args()
+    print(json.dumps(measure(args.hidden, args.n_actor, args.batch, args.graph)))
 
 
 if __name__ == '__main__':

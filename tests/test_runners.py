@@ -416,6 +416,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert line['cpu_baseline'].startswith('N=1 only') if 'cpu_baseline' in line else True
     assert e2e['collate_first_call_ms'] > 0         # the untimed warm-up collate
     assert line['other_shapes'] == 'N=1 only'       # the `shapes` leg is a one-GPU leg
+    assert line['config3_training'] == 'N=1 only'   # and so is the `learner` leg
 
 
 @pytest.mark.gpu
@@ -428,6 +429,7 @@ def test_bench_other_shapes_leg():
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = _last_json_line(out.stdout)
+    assert 'config3_training' not in line           # only the legs that were asked for
     shapes = line['other_shapes']
     assert set(shapes) == {'c2_K100', 'c3_env', 'c1_shape', 'c2_host_contract'}
     for name, o in shapes.items():
@@ -436,3 +438,18 @@ def test_bench_other_shapes_leg():
     assert shapes['c2_host_contract']['loop'].startswith('step(numpy)')
     # PCIe inclusive: slower than the device-resident loop on the same shape
     assert shapes['c2_host_contract']['value'] < 1.3e9
+
+
+@pytest.mark.gpu
+def test_bench_learner_leg():
+    """`bench.py --legs learner`: BASELINE config 3's training step (SAC, hidden
+    1024-1024, n_actor 65536) in the line."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--legs', 'learner',
+                          '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    t = _last_json_line(out.stdout)['config3_training']
+    assert t['n_actor'] == 65536 and t['hidden'] == '1024-1024' and t['batch'] == 4096
+    assert 0 < t['update_ms'] < t['train_step_ms']
+    assert t['train_streamline_steps_per_s'] > 0
