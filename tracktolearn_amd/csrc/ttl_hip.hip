@@ -593,6 +593,7 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
     __shared__ int red[BLOCK / 64];
     __shared__ unsigned s_key[BLOCK];
     __shared__ int s_pos[BLOCK];
+    __shared__ int s_rank[BLOCK];
     int before = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) before += P.proc_counts[b];
 #pragma unroll
@@ -640,28 +641,62 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
         const unsigned m = (spread3(vx) << 2) | (spread3(vy) << 1) | spread3(vz);
         key = ((coarse << 18 | m) << 8) | threadIdx.x;      // unique inside the block
     }
-    s_key[threadIdx.x] = key;
+    // Rank of this slot's key among the block's 256 keys (unique: the thread id
+    // sits in the low byte; idle threads of a partly filled last block share
+    // 0xFFFFFFFF and all rank behind the live ones).  Each wave sorts its 64 keys
+    // in registers (bitonic network over cross-lane exchanges, 21 stages), the
+    // four sorted runs go to LDS, and every key counts the smaller keys of the
+    // other three runs by binary search: 21 exchanges + 21 LDS reads per thread
+    // instead of 256 comparisons.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned sk = key;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)sk, stride);
+            const bool up = (lane & size) == 0;          // this block of `size` lanes ascends
+            const bool low = (lane & stride) == 0;       // the lower lane of the pair
+            const unsigned mn = min(sk, other), mx = max(sk, other);
+            sk = (up == low) ? mn : mx;
+        }
+    }
+    s_key[threadIdx.x] = sk;                 // run `wave`, ascending over the lanes
+    // sorted positions nobody ranks into (a partly filled last block: its idle
+    // threads all rank to the same position) must read as "no survivor": LDS
+    // keeps whatever an earlier workgroup left there
+    s_pos[threadIdx.x] = -1;
+    __syncthreads();
+    // position of the sorted key `sk`: its lane + the smaller keys of the other runs
+    int srank = lane;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        if (w == wave) continue;
+        const unsigned *run = s_key + 64 * w;
+        int c = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (run[c + step - 1] < sk) c += step;
+        if (c == 63 && run[63] < sk) c = 64;
+        srank += c;
+    }
+    // hand the position to the thread the key came from
+    if (sk != 0xFFFFFFFFu) s_rank[sk & 255u] = srank;
     __syncthreads();
     int rank = 0;
-    const uint4 *k4 = reinterpret_cast<const uint4 *>(s_key);
-#pragma unroll 8
-    for (int t = 0; t < BLOCK / 4; ++t) {
-        const uint4 q = k4[t];                 // same address in every lane: broadcast
-        rank += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
-    }
+    if (active) rank = s_rank[threadIdx.x];
     // sorted position `rank` of this block receives this slot's record
     if (active) {
         const size_t o = (size_t)blockIdx.x * BLOCK + rank;
         *reinterpret_cast<float4 *>(P.slot_head + 4 * o) = hd;
         P.slot_dest[o] = pd.y;
     }
-    s_pos[rank] = active ? pd.x : -1;            // surv_pos (or -1) in sorted order
+    if (active) s_pos[rank] = pd.x;              // surv_pos (or -1) in sorted order
     __syncthreads();
     // next step's order: the survivors, in this sorted order
     const int pos = s_pos[threadIdx.x];
     const bool keep = pos >= 0;
     const unsigned long long mk = __ballot(keep);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int below = __popcll(mk & ((1ull << lane) - 1ull));
     if (lane == 0) red[wave] = __popcll(mk);
     __syncthreads();
