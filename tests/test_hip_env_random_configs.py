@@ -9,10 +9,14 @@ pytestmark = pytest.mark.gpu
 
 
 def test_twelve_random_configurations():
+    import os
     import stress_parity
     from tracktolearn_amd.environments import TrackingEnvironment
-    saved = TrackingEnvironment.SPATIAL_ORDER_MIN
-    saved_refresh = TrackingEnvironment.SPATIAL_ORDER_REFRESH
+    # the stress script randomises class attributes and TTL_* environment knobs:
+    # put all of them back, the rest of the suite runs in this process
+    attrs = ('SPATIAL_ORDER_MIN', 'SPATIAL_ORDER_REFRESH', 'FREERUN_MAX', 'lazy_step_state')
+    saved = {a: getattr(TrackingEnvironment, a) for a in attrs}
+    saved_env = dict(os.environ)
     rng = np.random.RandomState(2024)
     stops = np.zeros(3, np.int64)
     try:
@@ -21,6 +25,11 @@ def test_twelve_random_configurations():
             stops += np.array(r['stops'])
             assert r['worst_state_err'] <= 1e-5
     finally:
-        TrackingEnvironment.SPATIAL_ORDER_MIN = saved
-        TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved_refresh
+        for a, v in saved.items():
+            setattr(TrackingEnvironment, a, v)
+        for key in [k for k in os.environ if k.startswith('TTL_') and k not in saved_env]:
+            del os.environ[key]
+        for key, v in saved_env.items():
+            if key.startswith('TTL_'):
+                os.environ[key] = v
     assert (stops > 0).all()      # mask, length and curvature stops all seen
