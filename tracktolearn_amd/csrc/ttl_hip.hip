@@ -639,7 +639,9 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
         // bits above the low 6 per axis first (coarse), then the Morton code
         const unsigned coarse = (((vx >> 6) & 3u) << 4) | (((vy >> 6) & 3u) << 2) | ((vz >> 6) & 3u);
         const unsigned m = (spread3(vx) << 2) | (spread3(vy) << 1) | spread3(vz);
-        key = ((coarse << 18 | m) << 8) | threadIdx.x;      // unique inside the block
+        // (the all-ones code -- voxel 255 / 511 / .. on every axis -- gives way by
+        // one, so that no live key equals the idle threads' 0xFFFFFFFF)
+        key = (min(coarse << 18 | m, 0xFFFFFEu) << 8) | threadIdx.x;   // unique inside the block
     }
     // Rank of this slot's key among the block's 256 keys (unique: the thread id
     // sits in the low byte; idle threads of a partly filled last block share
