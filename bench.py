@@ -491,6 +491,25 @@ def pipelined_windows(subject, device, seeds, parts, steps, warmup, n_win, seed,
             'value_max': total_units / float(t_all[0]), 'windows': len(t_all)}
 
 
+def other_shape(name, w, subject, device, args, seed, grp):
+    """One entry of the `shapes` leg: three windows of OTHER_SHAPES[name]."""
+    from tracktolearn_amd.utils.synthetic import synthetic_seeds
+    subj = subject if (subject is not None and w['D'] == D and not w.get('reward')
+                       and not w['noisy']) else make_subject(name)
+    env = make_env(subj, device, name)
+    env.seeds = synthetic_seeds(subj[1].data, w['n_total'], seed=100)
+    r = timed_windows(env, w['n_total'], args.steps, args.warmup, 3, seed, grp,
+                      host_contract=bool(w.get('host')))
+    return {
+        'what': w['what'], 'volume': [w['D']] * 3 + [C], 'n_actor': w['n_total'],
+        'n_dirs': w['n_dirs'],
+        'loop': 'step(numpy) + harvest' if w.get('host') else 'step_device + harvest',
+        'value': r['value'], 'ms_per_step': r['ms_per_step'],
+        'value_min': r['windows']['value_min'], 'value_max': r['windows']['value_max'],
+        'k_state_ms': r['state_ms'] / max(r['state_n'], 1), 'windows': 3,
+    }
+
+
 def kernel_breakdown(env, rows, steps, seed):
     """Untimed replay of a window with every kernel class bracketed (the timed
     windows only bracket the dominant kernel, to keep the event records out of
@@ -757,37 +776,29 @@ def main(argv=None):
 
     # ======================= the other BASELINE shapes (N = 1) =============
     if 'shapes' in legs and world == 1:
-        from tracktolearn_amd.utils.synthetic import synthetic_seeds
         shapes = {}
         for name, w in OTHER_SHAPES.items():
-            subj = subject if (subject is not None and w['D'] == D and not w.get('reward')
-                               and not w['noisy']) else make_subject(name)
-            env_s = make_env(subj, device, name)
-            env_s.seeds = synthetic_seeds(subj[1].data, w['n_total'], seed=100)
-            r = timed_windows(env_s, w['n_total'], args.steps, args.warmup, 3, seed, grp,
-                              host_contract=bool(w.get('host')))
-            shapes[name] = {
-                'what': w['what'], 'volume': [w['D']] * 3 + [C], 'n_actor': w['n_total'],
-                'n_dirs': w['n_dirs'],
-                'loop': 'step(numpy) + harvest' if w.get('host') else 'step_device + harvest',
-                'value': r['value'], 'ms_per_step': r['ms_per_step'],
-                'value_min': r['windows']['value_min'], 'value_max': r['windows']['value_max'],
-                'k_state_ms': r['state_ms'] / max(r['state_n'], 1), 'windows': 3,
-            }
-            del env_s
+            try:          # auxiliary one-GPU leg: never lose the headline line to it
+                shapes[name] = other_shape(name, w, subject, device, args, seed, grp)
+            except Exception as exc:
+                shapes[name] = {'what': w['what'], 'error': repr(exc)}
             torch.cuda.empty_cache()
         out['shapes'] = shapes
 
     # ======================= config 3: one SAC training step (N = 1) =======
     if 'learner' in legs and world == 1:
-        from benchmarks.bench_learner import measure as learner_measure
-        out['learner'] = learner_measure(device=device)
-        torch.cuda.empty_cache()
-        # the same with SACAuto.update replayed from a HIP graph (enable_graph())
-        graphed = learner_measure(device=device, graph=True)
-        out['learner']['graphed_update'] = {k: graphed[k] for k in
-                                            ('update_ms', 'train_step_ms',
-                                             'train_streamline_steps_per_s')}
+        # an auxiliary one-GPU leg: never lose the headline line to it
+        try:
+            from benchmarks.bench_learner import measure as learner_measure
+            out['learner'] = learner_measure(device=device)
+            torch.cuda.empty_cache()
+            # the same with SACAuto.update replayed from a HIP graph (enable_graph())
+            graphed = learner_measure(device=device, graph=True)
+            out['learner']['graphed_update'] = {k: graphed[k] for k in
+                                                ('update_ms', 'train_step_ms',
+                                                 'train_streamline_steps_per_s')}
+        except Exception as exc:
+            out['learner'] = dict(out.get('learner') or {}, error=repr(exc))
         torch.cuda.empty_cache()
 
     # ======================= 145^3 volume: config 4 + HBM regime ===========

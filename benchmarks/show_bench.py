@@ -30,9 +30,15 @@ if j.get('roofline_hbm_regime'):
           f"shard {r.get('value_rank0_shard', 0) / 1e6:.1f} M")
 if isinstance(j.get('other_shapes'), dict):
     for name, o in j['other_shapes'].items():
+        if 'error' in o:
+            print(f"{name}: {o['error']}")
+            continue
         print(f"{name}: {o['value'] / 1e6:.1f} M ({o['ms_per_step'] * 1e3:.1f} us/step, k_state {o['k_state_ms']:.4f} ms; {o['loop']})")
-if isinstance(j.get('config3_training'), dict):
-    t = j['config3_training']
+t = j.get('config3_training')
+if isinstance(t, dict) and 'error' in t:
+    print('config 3 training step:', t['error'])
+elif isinstance(t, dict):
+    g = t.get('graphed_update') or {}
     print(f"config 3 training step: {t['train_step_ms']:.2f} ms ({t['train_streamline_steps_per_s'] / 1e6:.1f} M streamline-steps/s), "
-          f"update alone {t['update_ms']:.2f} ms, sample {t['sample_ms']:.3f} ms; "
-          f"graphed update: step {t['graphed_update']['train_step_ms']:.2f} ms, update {t['graphed_update']['update_ms']:.2f} ms")
+          f"update alone {t['update_ms']:.2f} ms, sample {t['sample_ms']:.3f} ms"
+          + (f"; graphed update: step {g['train_step_ms']:.2f} ms, update {g['update_ms']:.2f} ms" if g else ''))
