@@ -18,7 +18,7 @@ window bracketed by barrier + torch.cuda.synchronize() on both sides and
 started from a fresh (untimed) reset, so all windows time the same K steps.
 `value` / `ms_per_step` are those of the MEDIAN window (max over ranks per
 window); min / max over the windows are printed next to them (`windows`).
-Every second window also brackets the dominant kernel with HIP events (for
+Every fourth window also brackets the dominant kernel with HIP events (for
 `roofline`); those records cost a few percent, both medians are printed.
 
 With N > 1 the driver launches one process per GPU (torch.distributed.run);
@@ -394,15 +394,16 @@ def timed_windows(env, rows, steps, warmup, n_win, seed, grp, host_contract=Fals
     if env._n_active:
         env._refresh_processing_order(force=True)
     torch.cuda.synchronize()
-    # The dominant kernel is bracketed with HIP events in every second window
-    # only: an event record costs ~6 us of GPU idle time on either side of the
-    # kernel (rocprofv3 trace, benchmarks/trace_gaps.py), ~5 % of a step.  All
-    # windows are timed alike and the value is the median over all of them.
+    # The dominant kernel is bracketed with HIP events in every fourth window
+    # only (3 of the default 11: 36 launches): an event record costs ~6 us of
+    # GPU idle time on either side of the kernel (rocprofv3 trace,
+    # benchmarks/trace_gaps.py), ~3-5 % of a step.  All windows are timed alike
+    # and the value is the median over all of them; both sub-medians are printed.
     times, n_units, resets = [], 0, 0
     state_ms, state_n, evented = 0.0, 0, []
     for w in range(n_win):
         counter = {'state': env.reset(0, rows), 'step': 0, 'resets': 0}
-        with_events = (w % 2 == 1) or n_win == 1
+        with_events = (w % 4 == 1) or n_win == 1
         if with_events:
             env.profile_begin(max_launches=steps + 8, classes=('state',))
         grp.barrier()
