@@ -259,3 +259,39 @@ def test_bench_refuses_unknown_legs():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--legs', 'weak,nope'],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and 'unknown leg' in out.stderr
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/ttl_hip.h is the C ABI: it must compile as pedantic C99 on its
+    own (no C++, no HIP, no torch types in any signature)."""
+    import shutil
+    import subprocess
+    cc = shutil.which('gcc')
+    if cc is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "ttl_hip.h"\n'
+                   'int main(void) { ttl_env_desc d; (void)d; return (int)sizeof(ttl_env *) * 0; }\n')
+    out = subprocess.run([cc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic',
+                          '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
+def test_c_host_example_builds_against_the_library():
+    """examples/ttl_track_c.c -- the C ABI driven from plain C, no Python / torch
+    in the process -- compiles with gcc -Wall -Wextra and links against the
+    in-tree libttl_hip.so (it runs under -m gpu, tests/test_runners.py)."""
+    import subprocess
+    from tracktolearn_amd.csrc import build as hip_build
+    try:
+        hip_build.find_hipcc()
+    except RuntimeError:
+        pytest.skip('no ROCm toolchain here')
+    if not os.path.exists(hip_build.OUTPUT):
+        hip_build.build()
+    exe = hip_build.build_example(verbose=False)
+    assert os.access(exe, os.X_OK)
+    needed = subprocess.run(['readelf', '-d', exe], capture_output=True, text=True).stdout
+    assert 'libttl_hip.so' in needed and 'libamdhip64' in needed
+    assert 'torch' not in needed and 'python' not in needed

@@ -453,3 +453,18 @@ def test_bench_learner_leg():
     assert t['n_actor'] == 65536 and t['hidden'] == '1024-1024' and t['batch'] == 4096
     assert 0 < t['update_ms'] < t['train_step_ms']
     assert t['train_streamline_steps_per_s'] > 0
+
+
+@pytest.mark.gpu
+def test_c_host_example_tracks_an_episode():
+    """The C ABI without Python in the process: examples/ttl_track_c (plain C99,
+    hipMalloc-ed buffers) tracks 20 000 streamlines to exhaustion through the
+    large-batch path (processing order, partly filled last workgroup) and
+    checks segment lengths, flags, lengths and the reported survivor counts."""
+    from tracktolearn_amd.csrc import build as hip_build
+    exe = hip_build.EXAMPLE_BIN
+    if not os.path.exists(exe):
+        exe = hip_build.build_example(verbose=False)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith('ok: 20000 streamlines'), out.stdout

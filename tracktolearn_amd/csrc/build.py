@@ -66,6 +66,31 @@ def build(force=False, verbose=True):
     return OUTPUT
 
 
+EXAMPLE_SRC = os.path.join(ROOT, 'examples', 'ttl_track_c.c')
+EXAMPLE_BIN = os.path.join(ROOT, 'examples', 'ttl_track_c')
+
+
+def build_example(verbose=True):
+    """examples/ttl_track_c: the C ABI driven from plain C99 (no Python, no
+    torch, compiled by gcc), linked against the in-tree libttl_hip.so and the
+    HIP runtime of the ROCm installation hipcc belongs to."""
+    rocm = os.path.dirname(os.path.dirname(os.path.realpath(find_hipcc())))
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if not cc:
+        raise RuntimeError('no C compiler (gcc) for examples/ttl_track_c')
+    cmd = [cc, '-std=c99', '-O2', '-Wall', '-Wextra', '-D__HIP_PLATFORM_AMD__',
+           '-I', os.path.join(rocm, 'include'), '-I', os.path.join(ROOT, 'include'),
+           EXAMPLE_SRC, '-L', PKG, '-lttl_hip', '-L', os.path.join(rocm, 'lib'), '-lamdhip64',
+           '-Wl,-rpath,$ORIGIN/../tracktolearn_amd', '-Wl,-rpath,' + os.path.join(rocm, 'lib'),
+           '-lm', '-o', EXAMPLE_BIN]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return EXAMPLE_BIN
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
     print(OUTPUT)
+    if '--example' in sys.argv:
+        print(build_example())
