@@ -54,6 +54,18 @@ def one(rng, k):
     os.environ['TTL_FUSE_MAX_ROWS'] = str(fuse_max)        # read when the handle is created ...
     TrackingEnvironment.FREERUN_MAX = fuse_max              # ... and by the host class at import
     TrackingEnvironment.lazy_step_state = bool(knobs3.randint(2))
+    # the step tail of batches with a processing order: rows and slots in one
+    # launch (the order keeps holes between refreshes) or the two-kernel tail;
+    # how many holes the host tolerates before it refreshes early
+    os.environ['TTL_TAIL_FUSED'] = str(knobs3.choice([0, 1, 1]))
+    TrackingEnvironment.ORDER_MIN_FILL = float(knobs3.choice([0.0, 0.5, 0.8, 0.99]))
+    if os.environ.get('TTL_STRESS_VERBOSE'):
+        print('config', k, dict(shape=shape, C=C, K=K, theta=theta, thr=thr, step=step_mm,
+                                noisy=noisy, reward=reward, N=N,
+                                order_min=TrackingEnvironment.SPATIAL_ORDER_MIN,
+                                refresh=TrackingEnvironment.SPATIAL_ORDER_REFRESH,
+                                knobs={v: os.environ[v] for v in sorted(os.environ)
+                                       if v.startswith('TTL_')}), flush=True)
     X, Y, Z = shape
     sh = (0.1 * rng.standard_normal((X, Y, Z, C))).astype(np.float32)
     g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing='ij'))

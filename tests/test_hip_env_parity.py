@@ -748,3 +748,59 @@ def test_caller_supplied_processing_orders_change_nothing(fused, sorter, monkeyp
         assert np.array_equal(env.streamlines, ref.streamlines)
     finally:
         TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved
+
+
+@pytest.mark.parametrize('tail,refresh,local_sort', [('1', 0, '1'), ('1', 4, '1'), ('1', 0, '0'),
+                                                     ('0', 4, '1')])
+def test_uncompacted_processing_order_changes_nothing(tail, refresh, local_sort, monkeypatch):
+    """Round 3: with the fused step tail (k_tail, TTL_TAIL_FUSED=1) the processing
+    order of a large batch is not compacted between refreshes -- stopped
+    streamlines leave holes that the per-block re-sort moves to the end of their
+    256-slot block and the gather skips.  A batch that is not a multiple of 256,
+    never refreshed (the holes only grow) or refreshed early once a fifth of
+    the slots are holes, with and without the re-sort, against the two-kernel
+    tail: every step equals the oracle's, the tractogram is bit-identical."""
+    monkeypatch.setenv('TTL_TAIL_FUSED', tail)
+    monkeypatch.setenv('TTL_LOCAL_SORT', local_sort)
+    from oracle import env_oracle as orc
+    from tracktolearn_amd.environments import TrackingEnvironment
+    saved = (TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH)
+    TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH = 1, refresh
+    try:
+        D, N = 20, 40000 + 77
+        sh, mask, pk = synthetic_subject(D)
+        rng = np.random.RandomState(11)
+        vox = np.argwhere(mask)
+        seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+        env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds, n_dirs=4,
+                       max_length=24.0, reward=False)
+        ref = orc.OracleTrackingEnv(sh, mask, seeds, n_dirs=4, theta=30.0,
+                                    step_size=env.step_size, max_nb_steps=env.max_nb_steps,
+                                    mask_threshold=0.1, peaks=pk, compute_reward=False,
+                                    alignment_weighting=1.0)
+        s_hip, s_ref = env.reset(0, N), ref.reset(0, N)
+        step, large_steps = 0, 0
+        while len(ref.continue_idx):
+            large_steps += env._n_active >= 16384 + 1
+            a = _scripted(rng, s_ref, 7 * 45, step, 0.1)
+            if step % 2:
+                ns_hip, _, d_hip, _ = env.step(a.copy())
+                ns = ns_hip.cpu().numpy()
+            else:
+                ns_hip, _, d_dev, info = env.step_device(torch.from_numpy(a).cuda())
+                ns = ns_hip.cpu().numpy()[info['row_dest'].cpu().numpy()]
+                d_hip = d_dev.cpu().numpy().astype(bool)
+            ns_ref, _, d_ref, _ = ref.step(a.copy())
+            assert np.array_equal(d_hip, d_ref), step
+            assert _close(ns, ns_ref), step
+            s_hip, _ = env.harvest()
+            s_ref, _ = ref.harvest()
+            assert np.array_equal(env.continue_idx, ref.continue_idx)
+            assert _close(s_hip.cpu().numpy(), s_ref), step
+            step += 1
+        assert large_steps >= 4          # the large-batch tail ran with holes in its order
+        assert np.array_equal(env.flags, ref.flags)
+        assert np.array_equal(env.lengths, ref.lengths)
+        assert np.array_equal(env.streamlines, ref.streamlines)
+    finally:
+        TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH = saved

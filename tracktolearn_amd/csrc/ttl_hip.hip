@@ -709,6 +709,159 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
     if (keep) proc_next[before + wave_before + below] = pos;
 }
 
+// ---------------------------------------------------------------------------
+// k_tail: k_prefix and k_proc_scatter in ONE launch (batches with a processing
+// order; TTL_TAIL_FUSED=1, opt-in: measured equal to the two-kernel tail within
+// the run-to-run spread, profiles/r03_tail_fused_ab.log).  What kept them apart was the stable
+// compaction of the processing order: a slot's new position needs the number
+// of surviving slots in every earlier block -- a second grid-wide prefix, over
+// slots, behind the first one over rows.  Here the order is NOT compacted
+// between its periodic refreshes: it keeps the length it had at the last
+// refresh (n_slots), a slot whose streamline has stopped becomes a hole (-1),
+// and the per-block re-sort moves the holes to the end of their 256-slot block,
+// where whole lane groups / waves of the gather exit at once.  Everything a
+// slot needs -- the row's position among the survivors, its state row -- then
+// follows from what k_advance left (stop, in-block rank, per-block counts): every
+// workgroup scans ALL block counts itself (<= 4096 ints through LDS), no
+// workgroup waits for another.
+// ---------------------------------------------------------------------------
+constexpr int TTL_TAIL_MAX_BLOCKS = 4096;
+
+__global__ __launch_bounds__(BLOCK) void k_tail(
+    EnvParams P, const int *__restrict__ idx, int *__restrict__ idx_next,
+    const int *__restrict__ proc, int *__restrict__ proc_next, int n_active, int n_slots,
+    int nb_rows, int order, int n_pts, int *__restrict__ host_word, int seq, int local_sort) {
+    __shared__ int s_scan[TTL_TAIL_MAX_BLOCKS];
+    __shared__ int s_wave[BLOCK / 64];
+    __shared__ unsigned s_key[BLOCK];
+    __shared__ int s_pos[BLOCK];
+    __shared__ int s_rank[BLOCK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- exclusive scan of the per-block survivor counts (rows) ----
+    const int per = (nb_rows + BLOCK - 1) / BLOCK;          // <= 16 counts per thread
+    const int lo = tid * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+        if (lo + k < nb_rows) sum += P.block_counts[lo + k];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int run = incl - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        if (w < wave) run += s_wave[w];
+        total += s_wave[w];
+    }
+    for (int k = 0; k < per; ++k)
+        if (lo + k < nb_rows) {
+            s_scan[lo + k] = run;
+            run += P.block_counts[lo + k];
+        }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {
+        P.counts[0] = total;
+        P.counts[1] = n_active - total;
+        if (host_word) {       // see k_prefix
+            __hip_atomic_store(host_word + 0, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_word + 1, n_active - total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_word + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // ---- rows: continue_idx of the next step, lengths, the row maps ----
+    const int i = blockIdx.x * BLOCK + tid;
+    if (i < n_active) {
+        const int pos = s_scan[blockIdx.x] + P.rank[i];
+        const bool stop = P.stop[i] != 0;
+        const int g = idx[i];
+        if (!stop) idx_next[pos] = g;
+        if (stop && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
+        P.surv_pos[i] = stop ? -1 : pos;
+        int dest = i;
+        if (order == TTL_ORDER_PARTITION) dest = stop ? total + (i - pos) : pos;
+        P.row_dest[i] = dest;
+    }
+    // ---- slots: this step's records for the gather, next step's order ----
+    const int j = i;
+    const int row = j < n_slots ? proc[j] : -1;
+    const bool live = row >= 0;
+    float4 hd = float4{0.f, 0.f, 0.f, 0.f};
+    int dest = -1, next = -1;
+    if (live) {
+        const bool stop = P.stop[row] != 0;
+        const int pos = s_scan[row / BLOCK] + P.rank[row];
+        dest = row;
+        if (order == TTL_ORDER_PARTITION) dest = stop ? total + (row - pos) : pos;
+        next = stop ? -1 : pos;
+        hd = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
+    }
+    if (!local_sort) {         // slots keep their places, holes included
+        if (j < n_slots) {
+            *reinterpret_cast<float4 *>(P.slot_head + 4 * (size_t)j) = hd;
+            P.slot_dest[j] = dest;
+            proc_next[j] = next;
+        }
+        return;
+    }
+    // per-block re-sort by the voxel the streamline sits in now (see
+    // k_proc_scatter); holes carry the largest key and end up behind the live slots
+    unsigned key = 0xFFFFFFFFu;
+    if (live) {
+        const unsigned vx = (unsigned)(int)fminf(fmaxf(floorf(hd.x), 0.0f), 1023.0f);
+        const unsigned vy = (unsigned)(int)fminf(fmaxf(floorf(hd.y), 0.0f), 1023.0f);
+        const unsigned vz = (unsigned)(int)fminf(fmaxf(floorf(hd.z), 0.0f), 1023.0f);
+        const unsigned coarse = (((vx >> 6) & 3u) << 4) | (((vy >> 6) & 3u) << 2) | ((vz >> 6) & 3u);
+        const unsigned m = (spread3(vx) << 2) | (spread3(vy) << 1) | spread3(vz);
+        key = (min(coarse << 18 | m, 0xFFFFFEu) << 8) | (unsigned)tid;
+    }
+    unsigned sk = key;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)sk, stride);
+            const bool up = (lane & size) == 0;
+            const bool low = (lane & stride) == 0;
+            const unsigned mn = min(sk, other), mx = max(sk, other);
+            sk = (up == low) ? mn : mx;
+        }
+    }
+    s_key[tid] = sk;
+    s_pos[tid] = -1;
+    const int n_live = __syncthreads_count(live);
+    int srank = lane;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        if (w == wave) continue;
+        const unsigned *srun = s_key + 64 * w;
+        int c = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (srun[c + step - 1] < sk) c += step;
+        if (c == 63 && srun[63] < sk) c = 64;
+        srank += c;
+    }
+    if (sk != 0xFFFFFFFFu) s_rank[sk & 255u] = srank;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * BLOCK;
+    if (live) {
+        const int rank = s_rank[tid];
+        *reinterpret_cast<float4 *>(P.slot_head + 4 * (base + rank)) = hd;
+        P.slot_dest[base + rank] = dest;
+        s_pos[rank] = next;
+    }
+    __syncthreads();
+    if (j < n_slots) {
+        if (tid >= n_live) P.slot_dest[j] = -1;        // the holes, behind the live slots
+        proc_next[j] = s_pos[tid];
+    }
+}
+
 // stopping flags of caller-supplied tails (n_pts points per streamline)
 __global__ __launch_bounds__(BLOCK) void k_probe_flags(
     EnvParams P, const float *__restrict__ tail, int n, int n_pts,
@@ -944,6 +1097,9 @@ struct ttl_env {
     size_t order_ws_bytes;
     int proc_cur;        // which proc buffer is current
     int use_proc;        // a processing order was installed for this episode
+    int n_slots;         // length of the processing order (>= n_active: with the fused tail it keeps
+                         // the length of its last refresh, stopped streamlines leave holes)
+    int tail_fused;      // k_tail instead of k_prefix + k_proc_scatter (TTL_TAIL_FUSED)
     // optional per-kernel timing with HIP events on the caller's stream
     int state_kernel; // 0: k_state (all 56 corner fetches), 3: k_state_dd with scalar tail stores, else k_state_dd
     hipStream_t side;      // carries the early device->host copy of the counts
@@ -1281,6 +1437,9 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
                                                      ? TTL_FUSE_MAX_BLOCKS * BLOCK : rows;
     }
     e->local_sort = 1;
+    e->tail_fused = 0;
+    if (const char *v = getenv("TTL_TAIL_FUSED")) e->tail_fused = atoi(v);
+    e->n_slots = 0;
     if (const char *v = getenv("TTL_LOCAL_SORT")) e->local_sort = atoi(v);
     e->poll_counts = 1;
     if (const char *v = getenv("TTL_POLL_COUNTS")) e->poll_counts = atoi(v);
@@ -1395,6 +1554,7 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
     env->fr_cap = 0;
     env->proc_cur = 0;
     env->use_proc = processing_order != nullptr;
+    env->n_slots = n;
     if (processing_order == TTL_ORDER_BY_POSITION) {
         // the library's own order: rows sorted by the brick of their seed
         const int rc = ttl_detail_refresh_order(env->P, d.idx_a, n, env->order_ws,
@@ -1541,30 +1701,53 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         if (host_counts && !host_word) HIP_TRY(ttl_copy_counts(env, host_counts, s));
         return TTL_OK;
     }
-    prof_mark(env, 1, 0, s);
-    hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
-                       proc, n_active, nb, order, n_pts, host_word, seq);
-    prof_mark(env, 1, 1, s);
-    HIP_TRY(hipGetLastError());
-    if (host_counts && !host_word) {
-        // fallback (buffer not device-visible): ship the count on a side stream
-        // as soon as k_prefix has run
-        HIP_TRY(ttl_copy_counts(env, host_counts, s));
-    }
-    if (proc) {
-        // next step's processing order: this one, compacted in its own order
-        // (ranks from k_prefix) and renumbered with the survivors' new row
-        // ids; plus this step's per-slot records for the gather
-        prof_mark(env, 3, 0, s);
-        hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, proc,
-                           env->proc[env->proc_cur ^ 1], n_active, nb,
-                           env->local_sort && env->P.slot_rec);
-        prof_mark(env, 3, 1, s);
+    // batches with a processing order: rows and slots in one launch (k_tail)
+    // when the gather reads per-slot records and the block counts fit its scan;
+    // the order then keeps its length between refreshes (holes), so the gather
+    // is launched for n_slots slots
+    int n_gather = n_active;
+    const bool fused_tail = proc && env->tail_fused && env->P.slot_rec &&
+                            ttl_detail_state_dedupes(env->P, env->state_kernel) &&
+                            (env->n_slots < 0 ? n_active : env->n_slots) <=
+                                TTL_TAIL_MAX_BLOCKS * BLOCK;
+    if (fused_tail) {
+        if (env->n_slots < 0) env->n_slots = n_active;     // the order was dense so far
+        const int nbs = (env->n_slots + BLOCK - 1) / BLOCK;
+        prof_mark(env, 1, 0, s);
+        hipLaunchKernelGGL(k_tail, dim3(nbs), dim3(BLOCK), 0, s, env->P, idx, idx_next, proc,
+                           env->proc[env->proc_cur ^ 1], n_active, env->n_slots, nb, order,
+                           n_pts, host_word, seq, env->local_sort);
+        prof_mark(env, 1, 1, s);
         HIP_TRY(hipGetLastError());
+        if (host_counts && !host_word) HIP_TRY(ttl_copy_counts(env, host_counts, s));
+        n_gather = env->n_slots;
+    } else {
+        prof_mark(env, 1, 0, s);
+        hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
+                           proc, n_active, nb, order, n_pts, host_word, seq);
+        prof_mark(env, 1, 1, s);
+        HIP_TRY(hipGetLastError());
+        if (host_counts && !host_word) {
+            // fallback (buffer not device-visible): ship the count on a side stream
+            // as soon as k_prefix has run
+            HIP_TRY(ttl_copy_counts(env, host_counts, s));
+        }
+        if (proc) {
+            // next step's processing order: this one, compacted in its own order
+            // (ranks from k_prefix) and renumbered with the survivors' new row
+            // ids; plus this step's per-slot records for the gather
+            prof_mark(env, 3, 0, s);
+            hipLaunchKernelGGL(k_proc_scatter, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, proc,
+                               env->proc[env->proc_cur ^ 1], n_active, nb,
+                               env->local_sort && env->P.slot_rec);
+            prof_mark(env, 3, 1, s);
+            HIP_TRY(hipGetLastError());
+            env->n_slots = -1;         // compacted: as long as the next step's active rows
+        }
     }
     prof_mark(env, 2, 0, s);
     const int rc = ttl_detail_launch_state(env->P, env->state_kernel, idx, env->P.row_dest,
-                                           proc, n_active, n_pts, state_out, state_pitch, s);
+                                           proc, n_gather, n_pts, state_out, state_pitch, s);
     prof_mark(env, 2, 1, s);
     return rc;
 }
@@ -1800,6 +1983,7 @@ int ttl_env_set_processing_order(ttl_env *env, const int32_t *order, int32_t n,
     HIP_TRY(hipMemcpyAsync(env->proc[env->proc_cur], order, (size_t)n * sizeof(int32_t),
                            hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
     env->use_proc = 1;
+    env->n_slots = n;
     return TTL_OK;
 }
 
@@ -1813,7 +1997,10 @@ int ttl_env_refresh_processing_order(ttl_env *env, void *hip_stream) {
     const int rc = ttl_detail_refresh_order(env->P, idx, env->n_active, env->order_ws,
                                             env->order_ws_bytes, env->proc[env->proc_cur],
                                             (hipStream_t)hip_stream);
-    if (rc == TTL_OK) env->use_proc = 1;
+    if (rc == TTL_OK) {
+        env->use_proc = 1;
+        env->n_slots = env->n_active;
+    }
     return rc;
 }
 

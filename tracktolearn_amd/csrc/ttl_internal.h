@@ -107,6 +107,9 @@ inline size_t ttl_detail_sh_records(const EnvParams &P) {
 int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx,
                             const int *row_dest, const int *proc, int n_rows, int L,
                             float *out, int64_t pitch, hipStream_t s);
+// ttl_state.hip: whether ttl_detail_launch_state() takes the register-deduplicated
+// gather (k_state_dd: reads the per-slot records of a processing order)
+bool ttl_detail_state_dedupes(const EnvParams &P, int state_kernel);
 // ttl_state.hip: the small-batch step tail (prefix + compaction + gather) in
 // one launch; host_word = device-visible pinned {n_continue, n_stopped, seq}
 // or null

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(BLOCK) void k_state(
     const int sub = lane - grp * LPS;
     if (grp >= GPW || slot >= n_rows) return;
     const int row = proc ? proc[slot] : slot;
+    if (row < 0) return;        // a hole of an uncompacted processing order
     const int g = idx ? idx[row] : row;
     const int r = row_dest ? row_dest[row] : row;
     const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
@@ -460,8 +461,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
         g = __float_as_int(hp.w);
         r = P.slot_dest[slot];
         row = 0;
+        if (r < 0) return;      // a hole of the uncompacted order (k_tail): nothing to gather
     } else {
         row = proc ? proc[slot] : slot;
+        if (row < 0) return;    // a hole of an uncompacted processing order
         g = idx ? idx[row] : row;
         r = row_dest ? row_dest[row] : row;
     }
@@ -651,15 +654,19 @@ int ttl_detail_launch_fused_tail_fr(const EnvParams &P, int *idx_a, int *idx_b, 
     return TTL_OK;
 }
 
+// the register-deduplicated kernel (the one that reads the per-slot records of a
+// processing order) needs the shifted points to stay within one cell of the
+// centre -- 0 < radius < 1 voxel -- and 32-bit byte offsets into the volume
+bool ttl_detail_state_dedupes(const EnvParams &P, int state_kernel) {
+    const size_t vol_bytes = ttl_detail_sh_records(P) * P.coef_pitch * sizeof(float);
+    return state_kernel != 0 && P.radius > 0.0f && P.radius < 1.0f && vol_bytes < (1ull << 32);
+}
+
 int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx,
                             const int *row_dest, const int *proc, int n_rows, int L,
                             float *out, int64_t pitch, hipStream_t s) {
     const int C4 = P.coef_pitch >> 2;
-    // the register-deduplicated kernel needs the shifted points to stay
-    // within one cell of the centre: 0 < radius < 1 voxel
-    const size_t vol_bytes = ttl_detail_sh_records(P) * P.coef_pitch * sizeof(float);
-    const bool dedupe = state_kernel != 0 && P.radius > 0.0f &&
-                        P.radius < 1.0f && vol_bytes < (1ull << 32);
+    const bool dedupe = ttl_detail_state_dedupes(P, state_kernel);
 #define TTL_LAUNCH_STATE(LPS)                                                 \
     do {                                                                      \
         const int rows_per_block = (BLOCK / 64) * (64 / LPS);                 \

@@ -201,6 +201,7 @@ class TrackingEnvironment(BaseEnv):
             self._state_pitch, self._stream()), 'ttl_env_reset')
         self._n_total = n
         self._n_active = n
+        self._order_slots = n if sort_rows else 0
         self._cur = 0
         self.length = 1
         self._pending = None
@@ -227,10 +228,22 @@ class TrackingEnvironment(BaseEnv):
         if n < self.SPATIAL_ORDER_MIN or self._pending is not None or \
                 not getattr(self, 'spatial_order', True):
             return
-        if not force and (not every or self.length <= 1 or (self.length - 1) % every):
+        # between refreshes the order keeps its length (the step's fused tail does
+        # not compact it: stopped streamlines leave holes at the end of their
+        # 256-slot block): refresh early once a fifth of it is holes
+        slots = getattr(self, '_order_slots', 0)
+        sparse = bool(every) and self.length > 1 and slots and n < self.ORDER_MIN_FILL * slots \
+            and os.environ.get('TTL_TAIL_FUSED', '0') == '1'
+        if not force and not sparse and \
+                (not every or self.length <= 1 or (self.length - 1) % every):
             return
         _lib.check(self._lib.ttl_env_refresh_processing_order(
             self._handle, self._stream()), 'ttl_env_refresh_processing_order')
+        self._order_slots = n
+
+    #: refresh the processing order early when fewer than this share of its slots
+    #: still hold a streamline
+    ORDER_MIN_FILL = float(os.environ.get('TTL_ORDER_MIN_FILL', '0.8'))
 
     def nreset(self, n_seeds: int):
         """N random seeds among all seeds (tracking_env.py:47-89; global
