@@ -57,7 +57,10 @@ def one(rng, k):
     # the step tail of batches with a processing order: rows and slots in one
     # launch (the order keeps holes between refreshes) or the two-kernel tail;
     # how many holes the host tolerates before it refreshes early
-    os.environ['TTL_TAIL_FUSED'] = str(knobs3.choice([0, 1, 1]))
+    tail_max = int(knobs3.choice([0, 98304, 1048576]))
+    os.environ['TTL_TAIL_FUSED'] = '1' if tail_max else '0'
+    os.environ['TTL_TAIL_FUSED_MAX_ROWS'] = str(max(tail_max, 1))
+    TrackingEnvironment.TAIL_FUSED_MAX_ROWS = tail_max
     TrackingEnvironment.ORDER_MIN_FILL = float(knobs3.choice([0.0, 0.5, 0.8, 0.99]))
     if os.environ.get('TTL_STRESS_VERBOSE'):
         print('config', k, dict(shape=shape, C=C, K=K, theta=theta, thr=thr, step=step_mm,

@@ -761,9 +761,11 @@ def test_uncompacted_processing_order_changes_nothing(tail, refresh, local_sort,
     the slots are holes, with and without the re-sort, against the two-kernel
     tail: every step equals the oracle's, the tractogram is bit-identical."""
     monkeypatch.setenv('TTL_TAIL_FUSED', tail)
+    monkeypatch.setenv('TTL_TAIL_FUSED_MAX_ROWS', '1048576')
     monkeypatch.setenv('TTL_LOCAL_SORT', local_sort)
     from oracle import env_oracle as orc
     from tracktolearn_amd.environments import TrackingEnvironment
+    monkeypatch.setattr(TrackingEnvironment, 'TAIL_FUSED_MAX_ROWS', 1048576 if tail == '1' else 0)
     saved = (TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH)
     TrackingEnvironment.SPATIAL_ORDER_MIN, TrackingEnvironment.SPATIAL_ORDER_REFRESH = 1, refresh
     try:

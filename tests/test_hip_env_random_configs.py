@@ -15,7 +15,7 @@ def test_twelve_random_configurations():
     # the stress script randomises class attributes and TTL_* environment knobs:
     # put all of them back, the rest of the suite runs in this process
     attrs = ('SPATIAL_ORDER_MIN', 'SPATIAL_ORDER_REFRESH', 'FREERUN_MAX', 'lazy_step_state',
-             'ORDER_MIN_FILL')
+             'ORDER_MIN_FILL', 'TAIL_FUSED_MAX_ROWS')
     saved = {a: getattr(TrackingEnvironment, a) for a in attrs}
     saved_env = dict(os.environ)
     rng = np.random.RandomState(2024)

@@ -711,8 +711,9 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
 
 // ---------------------------------------------------------------------------
 // k_tail: k_prefix and k_proc_scatter in ONE launch (batches with a processing
-// order; TTL_TAIL_FUSED=1, opt-in: measured equal to the two-kernel tail within
-// the run-to-run spread, profiles/r03_tail_fused_ab.log).  What kept them apart was the stable
+// order of at most TTL_TAIL_FUSED_MAX_ROWS slots, default 98 304: 3-4 % of a step
+// at 32 768-65 536 rows, within the run-to-run spread at 262 144, where it also
+// costs the gather 2 %: profiles/r03_tail_fused_ab.log; TTL_TAIL_FUSED=0: never).  What kept them apart was the stable
 // compaction of the processing order: a slot's new position needs the number
 // of surviving slots in every earlier block -- a second grid-wide prefix, over
 // slots, behind the first one over rows.  Here the order is NOT compacted
@@ -1099,7 +1100,8 @@ struct ttl_env {
     int use_proc;        // a processing order was installed for this episode
     int n_slots;         // length of the processing order (>= n_active: with the fused tail it keeps
                          // the length of its last refresh, stopped streamlines leave holes)
-    int tail_fused;      // k_tail instead of k_prefix + k_proc_scatter (TTL_TAIL_FUSED)
+    int tail_fused;      // k_tail instead of k_prefix + k_proc_scatter (TTL_TAIL_FUSED) ...
+    int tail_fused_max;  // ... for processing orders of at most this many slots (TTL_TAIL_FUSED_MAX_ROWS)
     // optional per-kernel timing with HIP events on the caller's stream
     int state_kernel; // 0: k_state (all 56 corner fetches), 3: k_state_dd with scalar tail stores, else k_state_dd
     hipStream_t side;      // carries the early device->host copy of the counts
@@ -1437,8 +1439,11 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
                                                      ? TTL_FUSE_MAX_BLOCKS * BLOCK : rows;
     }
     e->local_sort = 1;
-    e->tail_fused = 0;
+    e->tail_fused = 1;
     if (const char *v = getenv("TTL_TAIL_FUSED")) e->tail_fused = atoi(v);
+    e->tail_fused_max = 98304;
+    if (const char *v = getenv("TTL_TAIL_FUSED_MAX_ROWS")) e->tail_fused_max = atoi(v);
+    if (e->tail_fused_max > TTL_TAIL_MAX_BLOCKS * BLOCK) e->tail_fused_max = TTL_TAIL_MAX_BLOCKS * BLOCK;
     e->n_slots = 0;
     if (const char *v = getenv("TTL_LOCAL_SORT")) e->local_sort = atoi(v);
     e->poll_counts = 1;
@@ -1708,8 +1713,7 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
     int n_gather = n_active;
     const bool fused_tail = proc && env->tail_fused && env->P.slot_rec &&
                             ttl_detail_state_dedupes(env->P, env->state_kernel) &&
-                            (env->n_slots < 0 ? n_active : env->n_slots) <=
-                                TTL_TAIL_MAX_BLOCKS * BLOCK;
+                            (env->n_slots < 0 ? n_active : env->n_slots) <= env->tail_fused_max;
     if (fused_tail) {
         if (env->n_slots < 0) env->n_slots = n_active;     // the order was dense so far
         const int nbs = (env->n_slots + BLOCK - 1) / BLOCK;

@@ -233,7 +233,7 @@ class TrackingEnvironment(BaseEnv):
         # 256-slot block): refresh early once a fifth of it is holes
         slots = getattr(self, '_order_slots', 0)
         sparse = bool(every) and self.length > 1 and slots and n < self.ORDER_MIN_FILL * slots \
-            and os.environ.get('TTL_TAIL_FUSED', '0') == '1'
+            and slots <= self.TAIL_FUSED_MAX_ROWS
         if not force and not sparse and \
                 (not every or self.length <= 1 or (self.length - 1) % every):
             return
@@ -244,6 +244,10 @@ class TrackingEnvironment(BaseEnv):
     #: refresh the processing order early when fewer than this share of its slots
     #: still hold a streamline
     ORDER_MIN_FILL = float(os.environ.get('TTL_ORDER_MIN_FILL', '0.8'))
+    #: the library's fused tail (and with it the holes) is used for orders of at
+    #: most this many slots (mirrors TTL_TAIL_FUSED / TTL_TAIL_FUSED_MAX_ROWS)
+    TAIL_FUSED_MAX_ROWS = 0 if os.environ.get('TTL_TAIL_FUSED', '1') == '0' else \
+        int(os.environ.get('TTL_TAIL_FUSED_MAX_ROWS', '98304'))
 
     def nreset(self, n_seeds: int):
         """N random seeds among all seeds (tracking_env.py:47-89; global
