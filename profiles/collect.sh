@@ -28,13 +28,22 @@ for leg in weak hbm; do
   sfx=""; js=pmc_traffic.json
   if [ $leg = hbm ]; then sfx="_c4shard"; js=pmc_traffic_c4shard.json; fi
   B="python3 bench.py --no-cpu-baseline --no-whole-episode --legs $leg"
+  rm -f $O/stats$sfx.rows
+  export TTL_GATHER_ROWS_LOG=$O/stats$sfx.rows
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$sfx -- $B > $O/stats$sfx.json 2> $O/stats$sfx.log
+  # (the library logs the rows of every gather launch: with the fused step tail the
+  # grid of the gather covers more slots than rows; exported, not passed through
+  # `env`: nothing may sit between rocprofv3 and the program)
+  rm -f $O/fetch$sfx.rows $O/write$sfx.rows
+  export TTL_GATHER_ROWS_LOG=$O/fetch$sfx.rows
   $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch$sfx -- $B > $O/fetch$sfx.json 2> $O/fetch$sfx.log
+  export TTL_GATHER_ROWS_LOG=$O/write$sfx.rows
   $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write$sfx -- $B > $O/write$sfx.json 2> $O/write$sfx.log
+  unset TTL_GATHER_ROWS_LOG
   python3 profiles/pmc_summary.py ${tag}$sfx $O/stats$sfx $O/fetch$sfx $O/write$sfx $js
   cp $O/stats$sfx.json $R/${tag}${sfx}_bench_under_rocprof.json
   cp profiles/${tag}${sfx}_kernel_stats.csv profiles/${tag}${sfx}_pmc_traffic.txt profiles/$js $R/
-  rm -rf $O/stats$sfx $O/fetch$sfx $O/write$sfx
+  rm -rf $O/stats$sfx $O/fetch$sfx $O/write$sfx $O/fetch$sfx.rows $O/write$sfx.rows $O/stats$sfx.rows
 done
 $T python3 bench.py > $O/bench.json
 cp $O/bench.json $R/${tag}_bench.json

@@ -49,7 +49,21 @@ def search_launches(dirname):
         return 0
 
 
+def gather_rows_log(dirname):
+    """Rows every launch of the state gather really wrote, in launch order
+    (`<dirname>.rows`, written by the library under TTL_GATHER_ROWS_LOG: with the
+    fused step tail the gather's grid covers the slots of an uncompacted
+    processing order, more than its rows).  [] if the pass wrote none."""
+    path = dirname.rstrip('/') + '.rows'
+    if not os.path.exists(path):
+        return []
+    return [int(x) for x in open(path).read().split()]
+
+
 def counters(dirname, counter):
+    """{kernel: [(counter value, grid size or -rows), ...]} in dispatch order;
+    for the state gather the second entry is MINUS the true row count when the
+    pass logged one per launch (see units_of)."""
     path = glob.glob(os.path.join(dirname, '**', '*_counter_collection.csv'),
                      recursive=True)[0]
     per_dispatch = collections.defaultdict(lambda: [0.0, 0, ''])
@@ -59,9 +73,18 @@ def counters(dirname, counter):
             d[0] += float(r['Counter_Value'])
             d[1] = int(r['Grid_Size'])
             d[2] = short(r['Kernel_Name'])
+    true_rows = gather_rows_log(dirname)
+    n_gathers = sum(1 for d in per_dispatch.values() if d[2].startswith('k_state'))
+    if len(true_rows) != n_gathers:
+        true_rows = []
     rows = collections.defaultdict(list)
+    seen = 0
     for disp in sorted(per_dispatch):
         v, g, k = per_dispatch[disp]
+        if k.startswith('k_state'):
+            if true_rows:
+                g = -true_rows[seen]
+            seen += 1
         rows[k].append((v, g))
     skip = search_launches(dirname)
     for k in rows:
@@ -81,6 +104,9 @@ def durations_by_size(stats_dir):
     groups = collections.defaultdict(list)
     rows = sorted(csv.DictReader(open(paths[0])), key=lambda r: int(r['Start_Timestamp']))
     skip, seen = search_launches(stats_dir), 0
+    true_rows = gather_rows_log(stats_dir)
+    if len(true_rows) != sum(1 for r in rows if short(r['Kernel_Name']).startswith('k_state')):
+        true_rows = []
     for r in rows:
         k = short(r['Kernel_Name'])
         if not k.startswith('k_state'):
@@ -89,6 +115,8 @@ def durations_by_size(stats_dir):
         grid = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)
         m = re.match(r'k_state(?:_dd)?<(\d+)', k)
         units = grid // 256 * (4 * (64 // int(m.group(1))) if m else 20)
+        if true_rows:
+            units = true_rows[seen - 1]
         dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3      # us
         what = 'placement search (the first %d launches)' % skip if seen <= skip else \
             ('steps and resets of the windows (more than 200 000 rows)' if units > 200000
@@ -135,13 +163,16 @@ def main():
         # 4 waves x (64 // LPS) streamlines
         m = re.match(r'k_state(?:_dd)?<(\d+)', k)
         rows_per_block = 4 * (64 // int(m.group(1))) if m else 20
-        units = sum(g // 256 * rows_per_block for _, g in fetch.get(k, []))
+        logged = any(g < 0 for _, g in fetch.get(k, []))
+        units = sum(-g if g < 0 else g // 256 * rows_per_block for _, g in fetch.get(k, []))
         total = out[k]['hbm_bytes_per_launch'] * out[k]['launches']
         js['k_state_units_per_launch'] = units / max(out[k]['launches'], 1)
         js['k_state_hbm_bytes_per_unit'] = total / max(units, 1)
+        js['k_state_units_source'] = 'rows logged by the library per launch' if logged \
+            else 'grid sizes'
         lines.append(f'{k}: {js["k_state_units_per_launch"]:.0f} units/launch (from '
-                     f'the grid sizes) -> {js["k_state_hbm_bytes_per_unit"]:.1f} HBM '
-                     f'bytes per unit')
+                     f'{"the rows the library logged per launch" if logged else "the grid sizes"}'
+                     f') -> {js["k_state_hbm_bytes_per_unit"]:.1f} HBM bytes per unit')
     lines += durations_by_size(stats_dir)
     open(os.path.join(HERE, f'{tag}_pmc_traffic.txt'), 'w').write(
         '\n'.join(lines) + '\n')

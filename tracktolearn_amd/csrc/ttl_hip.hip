@@ -711,9 +711,10 @@ __global__ __launch_bounds__(BLOCK) void k_proc_scatter(EnvParams P,
 
 // ---------------------------------------------------------------------------
 // k_tail: k_prefix and k_proc_scatter in ONE launch (batches with a processing
-// order of at most TTL_TAIL_FUSED_MAX_ROWS slots, default 98 304: 3-4 % of a step
-// at 32 768-65 536 rows, within the run-to-run spread at 262 144, where it also
-// costs the gather 2 %: profiles/r03_tail_fused_ab.log; TTL_TAIL_FUSED=0: never).  What kept them apart was the stable
+// order of at most TTL_TAIL_FUSED_MAX_ROWS slots, default 262 144: 0-3 % of a step
+// at 262 144 rows depending on the box, 3-4 % at 32 768-65 536 rows; at 1 048 576
+// rows, where every workgroup scans 4 096 counts, it is 3 % SLOWER:
+// profiles/r03_tail_fused_ab.log; TTL_TAIL_FUSED=0: never).  What kept them apart was the stable
 // compaction of the processing order: a slot's new position needs the number
 // of surviving slots in every earlier block -- a second grid-wide prefix, over
 // slots, behind the first one over rows.  Here the order is NOT compacted
@@ -1127,6 +1128,22 @@ struct ttl_env {
     hipEvent_t *prof_ev[TTL_PROFILE_CLASSES];  // [2 * prof_cap] start/stop pairs
 };
 
+// Measurement support (profiles/pmc_summary.py): with TTL_GATHER_ROWS_LOG=<file>
+// every launch of the state gather appends the number of state rows it really
+// writes -- with the fused tail the gather's grid covers the slots of an
+// uncompacted processing order, more than the rows -- so that counter bytes can
+// be divided by units without reading them off the grid size.
+static void log_gather_rows(int n_rows) {
+    static FILE *f = []() -> FILE * {
+        const char *path = getenv("TTL_GATHER_ROWS_LOG");
+        return path && *path ? fopen(path, "a") : nullptr;
+    }();
+    if (f) {
+        fprintf(f, "%d\n", n_rows);
+        fflush(f);
+    }
+}
+
 static void prof_mark(ttl_env *e, int which, int stop, hipStream_t s) {
     if (!e->prof_on || !((e->prof_mask >> which) & 1) ||
         e->prof_n[which] >= e->prof_cap)
@@ -1441,7 +1458,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     e->local_sort = 1;
     e->tail_fused = 1;
     if (const char *v = getenv("TTL_TAIL_FUSED")) e->tail_fused = atoi(v);
-    e->tail_fused_max = 98304;
+    e->tail_fused_max = 262144;
     if (const char *v = getenv("TTL_TAIL_FUSED_MAX_ROWS")) e->tail_fused_max = atoi(v);
     if (e->tail_fused_max > TTL_TAIL_MAX_BLOCKS * BLOCK) e->tail_fused_max = TTL_TAIL_MAX_BLOCKS * BLOCK;
     e->n_slots = 0;
@@ -1569,6 +1586,7 @@ int ttl_env_reset(ttl_env *env, const float *seeds, int32_t n,
         HIP_TRY(hipMemcpyAsync(env->proc[0], processing_order, (size_t)n * sizeof(int32_t),
                                hipMemcpyDeviceToDevice, s));
     }
+    log_gather_rows(n);
     return ttl_detail_launch_state(env->P, env->state_kernel, nullptr, nullptr,
                                    env->use_proc ? env->proc[0] : nullptr, n, 1, state_out,
                                    state_pitch, s);
@@ -1750,6 +1768,7 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         }
     }
     prof_mark(env, 2, 0, s);
+    log_gather_rows(n_active);
     const int rc = ttl_detail_launch_state(env->P, env->state_kernel, idx, env->P.row_dest,
                                            proc, n_gather, n_pts, state_out, state_pitch, s);
     prof_mark(env, 2, 1, s);

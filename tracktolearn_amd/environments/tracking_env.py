@@ -247,7 +247,7 @@ class TrackingEnvironment(BaseEnv):
     #: the library's fused tail (and with it the holes) is used for orders of at
     #: most this many slots (mirrors TTL_TAIL_FUSED / TTL_TAIL_FUSED_MAX_ROWS)
     TAIL_FUSED_MAX_ROWS = 0 if os.environ.get('TTL_TAIL_FUSED', '1') == '0' else \
-        int(os.environ.get('TTL_TAIL_FUSED_MAX_ROWS', '98304'))
+        int(os.environ.get('TTL_TAIL_FUSED_MAX_ROWS', '262144'))
 
     def nreset(self, n_seeds: int):
         """N random seeds among all seeds (tracking_env.py:47-89; global
