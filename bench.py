@@ -538,6 +538,9 @@ def kernel_breakdown(env, rows, steps, seed):
     out = {k: prof[k][0] / n_steps for k in classes if k != 'state'}
     out['scripted_policy'] = sum(a.elapsed_time(b) for a, b in policy_ev) / max(len(policy_ev), 1)
     out['sum'] = sum(out.values())
+    # which tail ran: `prefix` is k_tail (rows + slots in one launch, no
+    # proc_scatter launches) or k_prefix next to k_proc_scatter
+    out['step_tail'] = 'k_tail' if prof['proc_scatter'][1] == 0 else 'k_prefix + k_proc_scatter'
     return out
 
 

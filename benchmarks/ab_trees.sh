@@ -18,7 +18,7 @@ for side in 'AB':
     d = json.load(open(f'gpurun_out/ab_{name}_{side}{r}.json'))
     roof = d['roofline']
     print(side, r, f"value {d['value']/1e6:.1f} M  ms/step {d['ms_per_step']:.4f}  k_state {roof['avg_launch_ms']:.4f}  "
-          f"other {json.dumps({k: round(v, 4) for k, v in roof['other_kernels_ms_per_step'].items()})}  "
+          f"other {json.dumps({k: round(v, 4) for k, v in roof['other_kernels_ms_per_step'].items() if not isinstance(v, str)})}  "
           f"episode {d['whole_episode']['streamline_steps_per_s_rank0']/1e6:.1f} M", flush=True)
 PY
 done

@@ -15,7 +15,7 @@ v, r = sys.argv[1:3]
 d = json.load(open(f'gpurun_out/tail_ab_{v}.json'))
 roof = d['roofline']
 print(v, r, f"value {d['value']/1e6:.1f} M  ms/step {d['ms_per_step']:.4f}  k_state {roof['avg_launch_ms']:.4f}  "
-      f"other {json.dumps({k: round(x, 4) for k, x in roof['other_kernels_ms_per_step'].items()})}  "
+      f"other {json.dumps({k: round(x, 4) for k, x in roof['other_kernels_ms_per_step'].items() if not isinstance(x, str)})}  "
       f"episode {d['whole_episode']['streamline_steps_per_s_rank0']/1e6:.1f} M", flush=True)
 PY
   done
