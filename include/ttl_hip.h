@@ -41,7 +41,7 @@ extern "C" {
 #define TTL_API
 #endif
 
-#define TTL_ABI_VERSION 9
+#define TTL_ABI_VERSION 10
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */

@@ -1,0 +1,443 @@
+"""The hand-scheduled SAC / SACAuto update (tracktolearn_amd/algorithms/shared/
+fused.py) against the autograd formulation of the reference's update
+(sac_auto.py:139-250, sac.py:135-232).
+
+CPU part: the schedule (arenas, batching, manual backward, Adam/Polyak over the
+arenas, the gradient autograd leaves on log_alpha) with the kernels replaced
+by their plain-torch restatement (tests/ref_learner_ops.py), in float64: any
+difference beyond rounding is a wrong formula.
+GPU part (-m gpu): every HIP kernel against its restatement on the same
+inputs, and the fused update on cuda:0 against the autograd update on cuda:0
+and against float64."""
+import copy
+
+import pytest
+import torch
+
+from ref_learner_ops import TorchOps
+
+CPU = torch.device('cpu')
+DEV = 'cuda:0'
+
+
+def _params(alg):
+    out = []
+    for net in (alg.agent.actor, alg.agent.critic, alg.target.actor, alg.target.critic):
+        out += list(net.named_parameters())
+    return out
+
+
+def _pair(cls, hidden, W, B, dtype, device=CPU, ops=None, seed=1):
+    torch.manual_seed(seed)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        a = cls(W, 3, hidden, n_actors=8, batch_size=B, replay_size=100, rng=None,
+                device=torch.device(device))
+        b = cls(W, 3, hidden, n_actors=8, batch_size=B, replay_size=100, rng=None,
+                device=torch.device(device))
+    finally:
+        torch.set_default_dtype(old)
+    b.agent.load_state_dict(a.agent.state_dict())
+    b.target.load_state_dict(a.target.state_dict())
+    if hasattr(a, 'log_alpha'):
+        b.log_alpha.data.copy_(a.log_alpha.data)
+    b._fused_ops = ops
+    return a, b
+
+
+def _batches(n, B, W, dtype, device=CPU, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        batch = [torch.randn(B, W, generator=g), torch.tanh(torch.randn(B, 3, generator=g)),
+                 torch.randn(B, W, generator=g), torch.rand(B, generator=g),
+                 (torch.rand(B, generator=g) > 0.2).float()]
+        eps = [torch.randn(B, 3, generator=g) for _ in range(2)]
+        out.append(([t.to(device, dtype) for t in batch], [e.to(device, dtype) for e in eps]))
+    return out
+
+
+def _inject(alg, eps):
+    it = iter(eps)
+    alg.noise_fn = lambda like: next(it)
+
+
+@pytest.mark.parametrize('cls_name,hidden', [('SACAuto', '32-32'), ('SACAuto', '16'),
+                                             ('SACAuto', '24-20-12'), ('SAC', '32-32')])
+def test_schedule_equals_autograd_in_float64(cls_name, hidden):
+    from tracktolearn_amd.algorithms.sac import SAC
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    cls = {'SAC': SAC, 'SACAuto': SACAuto}[cls_name]
+    W, B = 27, 64
+    ref, fused = _pair(cls, hidden, W, B, torch.float64, ops=TorchOps())
+    for batch, eps in _batches(3, B, W, torch.float64):
+        _inject(ref, eps)
+        _inject(fused, eps)
+        l_ref, l_fused = ref.update(batch), fused.update(batch)
+        assert fused._fused is not None and ref._fused is None
+        for (name, p), (_, q) in zip(_params(ref), _params(fused)):
+            assert torch.allclose(p, q, rtol=0, atol=1e-12), name
+            if p.grad is not None:
+                assert torch.allclose(p.grad, q.grad, rtol=1e-9, atol=1e-13), name
+        if cls is SACAuto:
+            assert l_ref == l_fused == {}
+            assert abs(float(ref.log_alpha.detach()) - float(fused.log_alpha.detach())) < 1e-13
+            # what autograd leaves on log_alpha.grad: d alpha_loss + d actor_loss
+            assert abs(float(ref.log_alpha.grad) - float(fused.log_alpha.grad)) < 1e-12
+        else:
+            assert set(l_ref) == set(l_fused)
+            for k in l_ref:
+                assert abs(float(l_ref[k]) - float(l_fused[k])) < 1e-12, k
+    assert fused.total_it == ref.total_it == 3
+
+
+def test_arena_views_keep_the_reference_surface(tmp_path):
+    """Parameters, gradients and optimizer state are views of the arenas: the
+    checkpoint keys, ``state_dict`` round trips, ``optimizer.state_dict`` and
+    ``zero_grad()`` behave as with the plain modules."""
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    W, B = 27, 64
+    ref, fused = _pair(SACAuto, '32-32', W, B, torch.float64, ops=TorchOps())
+    (batch, eps), (batch2, eps2) = _batches(2, B, W, torch.float64)
+    for alg in (ref, fused):
+        _inject(alg, eps)
+        alg.update(batch)
+    fu = fused._fused
+    w0 = fused.agent.actor.layers[0].weight
+    assert w0.data_ptr() == fu.arena_a.online.data_ptr()
+    assert w0.grad.data_ptr() == fu.arena_a.grad.data_ptr()
+    assert list(fused.agent.actor.state_dict()) == list(ref.agent.actor.state_dict())
+    assert list(fused.agent.critic.state_dict()) == list(ref.agent.critic.state_dict())
+    sd_ref, sd_fused = ref.actor_optimizer.state_dict(), fused.actor_optimizer.state_dict()
+    assert sd_ref['param_groups'][0]['params'] == sd_fused['param_groups'][0]['params']
+    for k in sd_ref['state']:
+        assert float(sd_fused['state'][k]['step']) == float(sd_ref['state'][k]['step']) == 1.0
+        assert torch.allclose(sd_ref['state'][k]['exp_avg'], sd_fused['state'][k]['exp_avg'],
+                              rtol=1e-9, atol=1e-14)
+    # save / load through the reference's file names, zero_grad, a foreign
+    # optimizer state: the next update still equals the autograd one
+    fused.agent.save(str(tmp_path), 'm')
+    fused.agent.load(str(tmp_path), 'm')
+    fused.actor_optimizer.zero_grad()
+    # (deep copy: load_state_dict aliases tensors that need no cast)
+    fused.critic_optimizer.load_state_dict(copy.deepcopy(ref.critic_optimizer.state_dict()))
+    assert w0.grad is None
+    for alg in (ref, fused):
+        _inject(alg, eps2)
+        alg.update(batch2)
+    assert w0.grad is not None
+    for (name, p), (_, q) in zip(_params(ref), _params(fused)):
+        assert torch.allclose(p, q, rtol=0, atol=1e-12), name
+    # a module moved / re-typed by the caller is re-homed, not silently stale
+    fused.agent.actor.double()
+    fused.agent.actor.layers[0].weight.data = fused.agent.actor.layers[0].weight.data.clone()
+    for alg in (ref, fused):
+        _inject(alg, eps)
+        alg.update(batch)
+    for (name, p), (_, q) in zip(_params(ref), _params(fused)):
+        assert torch.allclose(p, q, rtol=0, atol=1e-12), name
+
+
+def test_fused_path_needs_the_library_on_a_gpu_and_is_off_on_the_cpu(monkeypatch):
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    alg = SACAuto(27, 3, '32-32', n_actors=8, batch_size=16, replay_size=100, rng=None,
+                  device=CPU)
+    assert not alg._use_fused()                  # CPU: the autograd formulation
+    # a CUDA learner without the library fails loudly (no fallback)
+    from tracktolearn_amd import _lib
+    from tracktolearn_amd.algorithms.shared import fused
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libttl_hip.so')
+    with pytest.raises(_lib.TTLError):
+        fused.HipOps('cuda:0')
+
+
+# --------------------------------------------------------------------------
+# GPU: kernels against their restatements, update against autograd
+# --------------------------------------------------------------------------
+def _close(a, b, rtol, atol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), (what, float(err.max()), float((err / tol).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,H,A', [(8192, 1024, 3), (4096, 1024, 3), (100, 68, 2), (37, 45, 3),
+                                   (16, 2050, 4), (5, 7, 1)])
+def test_thin_forward_kernels(M, H, A):
+    from tracktolearn_amd.algorithms.shared.fused import (HEAD_PLAIN, HEAD_SAC, HEAD_TANH,
+                                                          THIN_FWD_ROWS, HipOps)
+    hip, ref = HipOps(DEV), TorchOps()
+    g = torch.Generator().manual_seed(M + H)
+    z = dict(device=DEV)
+    # strided rows (ld > H) as the side-by-side critic activations have
+    a = torch.randn(M, H + 8, generator=g).to(DEV)[:, :H]
+    w = (torch.randn(2 * A, H, generator=g) / H ** 0.5).to(DEV)
+    w[A:] *= 4                                             # some log_std beyond the clamp
+    b = torch.randn(2 * A, generator=g).to(DEV)
+    b[A:] += torch.tensor([-1.0, 3.0, -25.0, 0.0][:A], device=DEV)
+    eps = torch.randn(M, A, generator=g).to(DEV)
+    ent_rows = M // 2 + 3
+    outs = []
+    for ops in (hip, ref):
+        out = torch.zeros(M, A + 5, **z)
+        logp, raw = torch.zeros(M, **z), torch.zeros(M, A, **z)
+        part = torch.zeros(-(-M // THIN_FWD_ROWS), 1, **z)
+        ops.thin_forward(a, w, b, 2 * A, False, HEAD_SAC, out[:, 2:], A + 5, eps=eps,
+                         entropy_rows=ent_rows, logp=logp, ls_raw=raw, ent_part=part)
+        outs.append((out, logp, raw, part))
+    (o1, l1, r1, p1), (o2, l2, r2, p2) = outs
+    _close(o1, o2, 0, 2e-6, 'pi')
+    _close(r1, r2, 1e-5, 1e-5, 'log_std_raw')
+    _close(l1, l2, 2e-5, 2e-4, 'logp')
+    _close(p1.sum(), p2.sum(), 1e-5, 1e-2, 'entropy partials')
+    assert float(o1[:, :2].abs().max()) == 0 and float(o1[:, 2 + A:].abs().max()) == 0
+    # plain / tanh heads, dense and block-diagonal
+    for n_out, bd, head in ((2 * A, False, HEAD_PLAIN), (A, False, HEAD_TANH), (1, False, HEAD_PLAIN)):
+        res = []
+        for ops in (hip, ref):
+            out = torch.zeros(M, n_out + 1, **z)
+            ops.thin_forward(a, w[:n_out].contiguous(), b[:n_out].contiguous(), n_out, bd, head,
+                             out, n_out + 1)
+            res.append(out)
+        _close(res[0], res[1], 1e-5, 2e-5, (n_out, bd, head))
+    a2 = torch.randn(M, 2 * H, generator=g).to(DEV)
+    res = []
+    for ops in (hip, ref):
+        out = torch.zeros(M, 2, **z)
+        ops.thin_forward(a2, w[:2].contiguous(), b[:2].contiguous(), 2, True, HEAD_PLAIN, out, 2)
+        res.append(out)
+    _close(res[0], res[1], 1e-5, 2e-5, 'block diagonal')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,H', [(8192, 1024), (4096, 1024), (1000, 68), (37, 45), (9, 2050)])
+def test_backward_kernels(M, H):
+    from tracktolearn_amd.algorithms.shared.fused import HipOps, _rows_per_block
+    hip, ref = HipOps(DEV), TorchOps()
+    g = torch.Generator().manual_seed(M * 7 + H)
+    z = dict(device=DEV)
+    R = -(-M // _rows_per_block(M))
+    r0, r1 = M // 3, M - 2
+    # dense thin layer (actor head: 6 outputs)
+    a = torch.relu(torch.randn(M, H, generator=g)).to(DEV)
+    d_out = torch.randn(M, 6, generator=g).to(DEV)
+    w = torch.randn(6, H, generator=g).to(DEV)
+    res = []
+    for ops in (hip, ref):
+        dz, part = torch.zeros(M, H, **z), torch.full((R, H + 6 * H + 6), 7.0, **z)
+        ops.thin_backward(d_out, a, w, 6, False, r0, r1, dz, part)
+        res.append((dz, part))
+    _close(res[0][0], res[1][0], 1e-5, 1e-5, 'thin dense dz')
+    _close(res[0][1], res[1][1], 1e-4, 1e-4, 'thin dense slab')
+    _close(res[0][1].sum(0), res[1][1].sum(0), 1e-4, 2e-3, 'thin dense sums')
+    # block diagonal (the two critics side by side, ld > 2H)
+    a2 = torch.relu(torch.randn(M, 2 * H + 4, generator=g)).to(DEV)[:, :2 * H]
+    dq = torch.randn(M, 2, generator=g).to(DEV)
+    w2 = torch.randn(2, H, generator=g).to(DEV)
+    res = []
+    for ops in (hip, ref):
+        dz, part = torch.zeros(M, 2 * H, **z), torch.full((R, 4 * H + 2), 7.0, **z)
+        ops.thin_backward(dq, a2, w2, 2, True, r0, r1, dz, part)
+        res.append((dz, part))
+    _close(res[0][0], res[1][0], 1e-5, 1e-5, 'thin bd dz')
+    _close(res[0][1], res[1][1], 1e-4, 1e-4, 'thin bd slab')
+    # ReLU backward + bias partials
+    res = []
+    d0 = torch.randn(M, 2 * H, generator=g).to(DEV)
+    for ops in (hip, ref):
+        dz, part = d0.clone(), torch.full((R, 2 * H), 7.0, **z)
+        ops.relu_backward_bias(dz, a2, r0, r1, part)
+        res.append((dz, part))
+    assert torch.equal(res[0][0], res[1][0])
+    _close(res[0][1], res[1][1], 1e-4, 1e-4, 'relu slab')
+    # finalize: wide, narrow and scaled segments in one launch
+    part = res[0][1]
+    narrow = torch.randn(300, 8, generator=g).to(DEV)
+    res = []
+    for ops in (hip, ref):
+        o1, o2, o3 = torch.zeros(2 * H, **z), torch.zeros(8, **z), torch.zeros(1, **z)
+        ops.colsum_finalize([(part, 0, 2 * H, o1, 1.0), (narrow, 0, 8, o2, 0.25),
+                             (narrow[:77], 3, 1, o3, 1.0 / 77)])
+        res.append((o1, o2, o3))
+    for x, y in zip(*res):
+        _close(x, y, 1e-5, 1e-4, 'finalize')
+    # actor-loss gradient through the critics' first layer + head backward
+    dh = torch.randn(M, 2 * H, generator=g).to(DEV)
+    wa = torch.randn(3, 2 * H, generator=g).to(DEV)
+    pi = torch.tanh(torch.randn(M, 9, generator=g)).to(DEV)
+    eps = torch.randn(M, 3, generator=g).to(DEV)
+    raw = (torch.randn(M, 3, generator=g) * 8).to(DEV)
+    la = torch.tensor([-1.3], device=DEV)
+    for log_alpha, const in ((la, 0.0), (None, 0.2)):
+        res = []
+        for ops in (hip, ref):
+            d_head = torch.zeros(M, 6, **z)
+            ops.actor_head_backward(dh, a2, wa, 3, pi[:, 4:], 9, eps, raw, log_alpha, const, d_head)
+            res.append(d_head)
+        _close(res[0], res[1], 2e-5, 2e-5 * float(res[1].abs().max()), 'head backward')
+
+
+@pytest.mark.gpu
+def test_losses_adam_and_input_kernels():
+    from tracktolearn_amd.algorithms.shared.fused import LOSS_BLOCK, HipOps
+    hip, ref = HipOps(DEV), TorchOps()
+    g = torch.Generator().manual_seed(5)
+    z = dict(device=DEV)
+    for n in (4096, 1000, 7):
+        q_on = torch.randn(2 * n, 2, generator=g).to(DEV)
+        q_on[n + 1, 1] = q_on[n + 1, 0]                      # a tie of the two critics
+        q_tg = torch.randn(n, 2, generator=g).to(DEV)
+        logp = torch.randn(2 * n, generator=g).to(DEV)
+        r, nd = torch.rand(n, generator=g).to(DEV), (torch.rand(n, generator=g) > 0.2).float().to(DEV)
+        la = torch.tensor([-1.6], device=DEV)
+        for log_alpha, const, mask in ((la, 0.0, 0b111), (None, 0.2, 0b110)):
+            res = []
+            for ops in (hip, ref):
+                dq = torch.zeros(2 * n, 2, **z)
+                part = torch.zeros(-(-n // LOSS_BLOCK), 8, **z)
+                steps = torch.tensor([4.0, 9.0, 0.0], **z)
+                consts = torch.zeros(6, **z)
+                ops.sac_losses(q_on, q_tg, logp, r, nd, log_alpha, const, 0.99, dq, part, steps,
+                               consts, mask, 3e-4)
+                res.append((dq, part.sum(0), steps, consts))
+            assert torch.equal(res[0][2], res[1][2])
+            _close(res[0][0], res[1][0], 1e-6, 1e-9, 'dq')
+            _close(res[0][1], res[1][1], 1e-5, 1e-3, 'loss sums')
+            _close(res[0][3], res[1][3], 1e-6, 0, 'adam scalars')
+    # Adam + Polyak over an arena whose length is not a multiple of 4
+    n = 1000003
+    p0, g0 = torch.randn(n + 1, generator=g).to(DEV)[:n], torch.randn(n + 1, generator=g).to(DEV)[:n]
+    m0, v0 = 0.1 * torch.randn(n + 1, generator=g).to(DEV)[:n], torch.rand(n + 1, generator=g).to(DEV)[:n]
+    t0 = torch.randn(n + 1, generator=g).to(DEV)[:n]
+    consts = torch.tensor([3e-4 / (1 - 0.9 ** 3), (1 - 0.999 ** 3) ** 0.5], **z)
+    res = []
+    for ops in (hip, ref):
+        p, m, v, t = p0.clone(), m0.clone(), v0.clone(), t0.clone()
+        ops.adam_polyak(p, g0, m, v, t, consts, 0.005)
+        res.append((p, m, v, t))
+    for x, y, what in zip(res[0], res[1], 'pmvt'):
+        _close(x, y, 1e-6, 1e-7, 'adam ' + what)
+    # torch.optim.Adam itself, three steps from scratch
+    w = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([w], lr=3e-4)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    steps, consts = torch.zeros(1, **z), torch.zeros(2, **z)
+    dummy = torch.zeros(2, 2, **z)
+    for it in range(3):
+        gi = torch.randn(n, generator=g).to(DEV)
+        w.grad = gi.clone()
+        opt.step()
+        hip.sac_losses(dummy, dummy[:1], dummy.view(-1)[:2], dummy[0, :1], dummy[0, :1], None, 0.2,
+                       0.99, torch.zeros(2, 2, **z), None, steps, consts, 0b1, 3e-4)
+        hip.adam_polyak(p, gi, m, v, None, consts, 0.0)
+    assert float(steps) == 3.0
+    _close(p, w.data, 0, 1e-7, 'three Adam steps vs torch.optim.Adam')
+    # temperature step
+    res = []
+    for ops in (hip, ref):
+        la, gr = torch.tensor([-1.6], **z), torch.zeros(1, **z)
+        m, v = torch.tensor([0.3], **z), torch.tensor([2.0], **z)
+        ops.alpha_step(la, gr, m, v, torch.tensor([-2.2], **z), -3.0,
+                       torch.tensor([3e-4 / (1 - 0.9 ** 2), (1 - 0.999 ** 2) ** 0.5], **z))
+        res.append(torch.cat([la, gr, m, v]))
+    _close(res[0], res[1], 1e-6, 1e-8, 'alpha step')
+    # network input rows
+    n, S, A = 1000, 327, 3
+    s, a, s2 = (torch.randn(n, k, generator=g).to(DEV) for k in (S, A, S))
+    w1 = torch.randn(2048, S + A, generator=g).to(DEV)
+    res = []
+    for ops in (hip, ref):
+        xs, wa = torch.full((3 * n, 332), 9.0, **z), torch.zeros(A, 2048, **z)
+        ops.build_inputs(s, a, s2, xs, S, A, w1, wa)
+        res.append((xs, wa))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def _grad_err(g, g64):
+    g, g64 = g.detach().double().cpu(), g64.detach().double().cpu()
+    return float((g - g64).norm() / (g64.norm() + 1e-300))
+
+
+def _sync(dst, src, dtype, device):
+    """dst <- src: weights, targets, temperature and optimizer state."""
+    for name in ('agent', 'target'):
+        sd_a, sd_c = getattr(src, name).state_dict()
+        getattr(dst, name).load_state_dict(({k: v.to(device, dtype) for k, v in sd_a.items()},
+                                            {k: v.to(device, dtype) for k, v in sd_c.items()}))
+    if hasattr(src, 'log_alpha'):
+        dst.log_alpha.data.copy_(src.log_alpha.data.to(device, dtype))
+    for od, os_ in zip(dst._optimizers(), src._optimizers()):
+        od.load_state_dict(copy.deepcopy(os_.state_dict()))
+    dst.total_it = src.total_it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cls_name,hidden,W,B', [('SACAuto', '1024-1024', 327, 4096),
+                                                 ('SACAuto', '256-192-128', 615, 1000),
+                                                 ('SAC', '128', 45, 333)])
+def test_fused_update_on_the_gpu_matches_autograd(cls_name, hidden, W, B, monkeypatch):
+    """cuda:0: FusedSACUpdate (HIP kernels + GEMMs) against the autograd
+    update on the same device and against a float64 CPU run, two updates (the
+    second with Adam moments in place; before it the two referees are synced to
+    the fused learner's state, optimizers included): gradients within 5e-3 in
+    L2 of float64 (ReLU / min decisions within rounding of their boundary route
+    a row differently; typical tensors 1e-6), parameters >= 99.8 % of the
+    entries within 1e-5 of the autograd result, none beyond 2 lr."""
+    from tracktolearn_amd.algorithms.sac import SAC
+    from tracktolearn_amd.algorithms.sac_auto import SACAuto
+    cls = {'SAC': SAC, 'SACAuto': SACAuto}[cls_name]
+    ref64, _ = _pair(cls, hidden, W, B, torch.float64)
+    monkeypatch.setenv('TTL_FUSED_LEARNER', '0')
+    plain, _ = _pair(cls, hidden, W, B, torch.float32, device=DEV)
+    monkeypatch.setenv('TTL_FUSED_LEARNER', '1')
+    fused, _ = _pair(cls, hidden, W, B, torch.float32, device=DEV)
+    for alg in (plain, fused):
+        _sync(alg, ref64, torch.float32, DEV)
+    lr = 3e-4
+    for u, (batch, eps) in enumerate(_batches(2, B, W, torch.float64)):
+        if u:
+            _sync(plain, fused, torch.float32, DEV)
+            _sync(ref64, fused, torch.float64, 'cpu')
+        _inject(ref64, eps)
+        ref64.update(batch)
+        b32 = [t.float().to(DEV) for t in batch]
+        for alg in (plain, fused):
+            _inject(alg, [e.float().to(DEV) for e in eps])
+            alg.update(b32)
+        assert fused._fused is not None and plain._fused is None
+        worst = 0.0
+        for (name, p64), (_, pp), (_, pf) in zip(_params(ref64), _params(plain), _params(fused)):
+            if p64.grad is not None:
+                e_f, e_p = _grad_err(pf.grad, p64.grad), _grad_err(pp.grad, p64.grad)
+                worst = max(worst, e_f)
+                assert e_f <= 5e-3, (u, name, e_f, e_p)
+            d = (pf.detach() - pp.detach()).abs()
+            assert float(d.max()) <= 2 * lr, (u, name, float(d.max()))
+            assert float((d <= 1e-5).float().mean()) >= 0.998, (u, name)
+        if cls is SACAuto:
+            assert abs(float(fused.log_alpha.detach()) - float(plain.log_alpha.detach())) <= 1e-6
+            assert _grad_err(fused.log_alpha.grad, ref64.log_alpha.grad) <= 1e-5
+        print(f'{cls_name} {hidden} update {u}: worst gradient L2 error vs float64 {worst:.2e}')
+    assert fused.total_it == plain.total_it == 2
+
+
+@pytest.mark.gpu
+def test_fused_sac_losses_dict_matches_autograd(monkeypatch):
+    from tracktolearn_amd.algorithms.sac import SAC
+    W, B = 64, 512
+    monkeypatch.setenv('TTL_FUSED_LEARNER', '0')
+    plain, _ = _pair(SAC, '64-64', W, B, torch.float32, device=DEV)
+    monkeypatch.setenv('TTL_FUSED_LEARNER', '1')
+    fused, _ = _pair(SAC, '64-64', W, B, torch.float32, device=DEV)
+    fused.agent.load_state_dict(plain.agent.state_dict())
+    fused.target.load_state_dict(plain.target.state_dict())
+    (batch, eps), = _batches(1, B, W, torch.float32, device=DEV)
+    _inject(plain, eps)
+    _inject(fused, eps)
+    lp, lf = plain.update(batch), fused.update(batch)
+    assert set(lp) == set(lf)
+    for k in lp:
+        assert abs(float(lp[k]) - float(lf[k])) <= 1e-5 * max(1.0, abs(float(lp[k]))), k

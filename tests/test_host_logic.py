@@ -14,9 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     from tracktolearn_amd import _lib
-    header = open(os.path.join(ROOT, 'include', 'ttl_hip.h')).read()
-    body = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
-    declared = set(re.findall(r'\b(ttl_[a-z_]+)\s*\(', body))
+    declared = set()
+    for name in ('ttl_hip.h', 'ttl_learner.h'):
+        header = open(os.path.join(ROOT, 'include', name)).read()
+        body = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+        declared |= set(re.findall(r'\b(ttl_[a-z_]+)\s*\(', body))
     assert declared, 'no declarations parsed'
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     lib = _lib.load()

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (keep above the CDLL below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 SH_LINEAR, SH_BRICK4 = 0, 1
 MODE_F32 = 0
 MODE_F64DIR = 1
@@ -70,7 +70,21 @@ class EnvDesc(C.Structure):
     ]
 
 
-# name -> (restype, argtypes); every symbol include/ttl_hip.h declares
+class ColsumSeg(C.Structure):
+    """struct ttl_colsum_seg (include/ttl_learner.h)."""
+    _fields_ = [
+        ('part', C.c_void_p),
+        ('ld', C.c_int64),
+        ('n_part', C.c_int32),
+        ('n', C.c_int32),
+        ('out', C.c_void_p),
+        ('scale', C.c_float),
+        ('accumulate', C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ttl_hip.h and
+# include/ttl_learner.h declare
 SYMBOLS = {
     'ttl_env_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'ttl_sh_volume_records': (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),
@@ -131,6 +145,37 @@ SYMBOLS = {
                                            C.c_int32, C.c_void_p, C.c_void_p]),
     'ttl_pack_streamlines': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_void_p, C.c_void_p]),
+    # ---- include/ttl_learner.h
+    'ttl_thin_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    'ttl_sac_losses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32,
+                                 C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    'ttl_thin_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int64, C.c_void_p]),
+    'ttl_relu_backward_bias': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_int64, C.c_void_p]),
+    'ttl_colsum_finalize': (C.c_int, [C.POINTER(ColsumSeg), C.c_int32, C.c_void_p]),
+    'ttl_sac_actor_head_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    'ttl_adam_polyak': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_void_p]),
+    'ttl_sac_alpha_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float,
+                                     C.c_float, C.c_void_p]),
+    'ttl_build_learner_inputs': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                           C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'ttl_last_error': (C.c_char_p, []),
     'ttl_abi_version': (C.c_uint32, []),
     'ttl_env_desc_size': (C.c_size_t, []),

@@ -1,4 +1,12 @@
-"""SAC with a fixed temperature -- mirror of TrackToLearn/algorithms/sac.py."""
+"""SAC with a fixed temperature -- mirror of TrackToLearn/algorithms/sac.py.
+
+On a CUDA device ``update`` runs as ``shared/fused.py``'s hand-scheduled
+forward/backward (GEMMs on PyTorch-ROCm + the HIP learner kernels of
+libttl_hip.so, include/ttl_learner.h); on the CPU (known-answer tests) as the
+autograd formulation below, which is also what ``TTL_FUSED_LEARNER=0`` keeps on
+the GPU for A/B measurements."""
+import os
+
 import torch
 
 from tracktolearn_amd.algorithms.ddpg import DDPG
@@ -21,6 +29,10 @@ class SAC(DDPG):
         self.noise_fn = None
         self._graph = None
         self._graph_batch = None
+        #: shared/fused.py's FusedSACUpdate, built at the first update on a
+        #: CUDA device (there is no fused CPU path)
+        self._fused = None
+        self._fused_ops = None          # test seam: a stand-in for HipOps
         # data-parallel learner (``enable_data_parallel``): every rank samples
         # its own replay ring and the gradients are averaged over the process
         # group before each optimizer step; DDPG._schedule keeps the number of
@@ -144,8 +156,27 @@ class SAC(DDPG):
         self.critic_optimizer.step()
         self._polyak()
 
+    def _use_fused(self):
+        if self._fused is not None:
+            return True
+        dev = torch.device(self.device)
+        if self._fused_ops is None and (
+                dev.type != 'cuda' or os.environ.get('TTL_FUSED_LEARNER', '1') == '0'):
+            return False
+        from tracktolearn_amd.algorithms.shared.fused import FusedSACUpdate
+        self._fused = FusedSACUpdate(self, ops=self._fused_ops)
+        return True
+
+    def _update_fused(self, batch, want_losses):
+        # the two gaussian draws in the reference's order: pi(s), then pi(s')
+        eps_pi, eps_next = self._eps(batch[1]), self._eps(batch[1])
+        with torch.no_grad():
+            return self._fused.update(batch, eps_pi, eps_next, want_losses=want_losses)
+
     def _update_impl(self, batch):
         """sac.py:135-232."""
+        if self._use_fused():
+            return self._update_fused(batch, want_losses=True)
         state = batch[0]
         pi, logp_pi = self.agent.act(state, probabilistic=1.0,
                                      eps=self._eps(batch[1]))

@@ -30,6 +30,8 @@ class SACAuto(SAC):
         """sac_auto.py:139-250: temperature, actor, critic steps in that
         order, then Polyak averaging of critic and actor targets.  Returns an
         empty dict, as the reference does (all its entries are commented)."""
+        if self._use_fused():
+            return self._update_fused(batch, want_losses=False)
         state = batch[0]
         pi, logp_pi = self.agent.act(state, probabilistic=1.0,
                                      eps=self._eps(batch[1]))

@@ -1,0 +1,528 @@
+"""The MI355X form of one SAC / SACAuto gradient update.
+
+The reference's update (TrackToLearn/algorithms/sac_auto.py:139-250,
+sac.py:135-232) is PyTorch autograd over three MLPs + three
+``torch.optim.Adam`` steps + a per-parameter Polyak loop.  At config 3's
+shapes (W = 327, hidden 1024-1024, batch 4 096) that is ~40 GEMMs and ~110
+small kernels, and 40 % of the GPU time is in the small ones
+(``profiles/r03``: 600 bias-gradient reductions, 2 000 adds, ReLU-backward
+masks, unfused Adam).  ``FusedSACUpdate`` computes the same update as a
+hand-scheduled forward/backward:
+
+* **memory**: every network's parameters live in ONE flat fp32 arena (online,
+  target, gradient, Adam first and second moment: five arenas with the same
+  layout), the ``nn.Parameter``s, their ``.grad`` and the optimizer's state
+  tensors are views into them, so checkpoints, ``state_dict`` and
+  ``optimizer.state_dict`` read as before, while Adam + Polyak is one kernel
+  over the arena and the data-parallel gradient average one all-reduce per
+  network without a flatten copy.  The two critics are interleaved layer by
+  layer so that their first layers are ONE GEMM ([2h x (W+3)] stacked weights)
+  and their activations sit side by side ([rows x 2h]).
+* **batching**: the rows the three forwards consume come from one buffer
+  ``xs`` [3B x ld]: rows [0,B) = (s, a), [B,2B) = (s, pi(s)), [2B,3B) =
+  (s', pi(s')); the actor runs once on rows [B,3B) (2B rows), the online
+  critics once on rows [0,2B), the target critics on rows [2B,3B): 12 GEMMs
+  instead of ~40, all with 4 096-8 192 rows.
+* **everything that is not a dense GEMM** is a hand-written HIP kernel of
+  libttl_hip.so (include/ttl_learner.h): the 6-wide actor head with the
+  squashed-gaussian sample / log-probability, the 1-wide critic heads, the
+  per-row losses, the thin layers' backward fused with the ReLU mask and the
+  bias / weight-gradient column sums, ReLU-backward + bias gradient, the
+  actor-loss gradient through the critics' first layer, Adam + Polyak.
+  Reductions are deterministic (slab partials, fixed order).
+
+The GEMMs stay on PyTorch-ROCm (hipBLASLt fp32 MFMA, north_star) with the
+bias + ReLU epilogue (``torch._addmm_activation``) and preallocated outputs.
+fp32 throughout.  There is no CPU form of this path: on a CUDA device the
+kernels are required (``_lib.load()`` raises without the library); on the
+CPU (the known-answer tests) SAC keeps the plain autograd update.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from tracktolearn_amd import _lib
+
+try:                                    # no Stream object per call
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                  # pragma: no cover
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+HEAD_PLAIN, HEAD_SAC, HEAD_TANH = 0, 1, 2
+THIN_FWD_ROWS = 16
+LOSS_BLOCK = 256
+BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
+#: slab rows (row blocks) of the backward kernels: enough workgroups to fill
+#: the 256 CUs, few enough for the fixed-order finalize to stay a few us
+SLAB_ROWS = 128
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _rows_per_block(n_rows):
+    return max(4, -(-n_rows // SLAB_ROWS))
+
+
+class HipOps:
+    """The learner kernels of libttl_hip.so, called with torch tensors.
+    (The tests substitute a plain-torch restatement, tests/ref_learner_ops.py,
+    to check the schedule below on the CPU against autograd.)"""
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.index = torch.device(device).index or 0
+
+    def _s(self):
+        return C.c_void_p(_raw_stream(self.index))
+
+    def thin_forward(self, a, w, b, n_out, block_diagonal, head, out, ld_out, eps=None,
+                     entropy_rows=0, logp=None, ls_raw=None, ent_part=None):
+        n_rows = a.shape[0]
+        n_in = a.shape[1] // n_out if block_diagonal else a.shape[1]
+        assert a.stride(1) == 1 and w.is_contiguous() and w.numel() == n_out * n_in
+        _lib.check(self.lib.ttl_thin_forward(
+            _ptr(a), a.stride(0), _ptr(w), _ptr(b), n_rows, n_in, n_out, int(block_diagonal),
+            head, _ptr(eps) if eps is not None else None, entropy_rows, _ptr(out), ld_out,
+            _ptr(logp) if logp is not None else None,
+            _ptr(ls_raw) if ls_raw is not None else None,
+            _ptr(ent_part) if ent_part is not None else None, self._s()), 'ttl_thin_forward')
+
+    def sac_losses(self, q_on, q_tg, logp, reward, not_done, log_alpha, alpha_const, gamma,
+                   dq, loss_part, steps, consts, tick_mask, lr):
+        n = reward.shape[0]
+        _lib.check(self.lib.ttl_sac_losses(
+            _ptr(q_on), _ptr(q_tg), _ptr(logp), _ptr(reward), _ptr(not_done), n,
+            _ptr(log_alpha) if log_alpha is not None else None, float(alpha_const),
+            float(gamma), _ptr(dq), _ptr(loss_part) if loss_part is not None else None,
+            _ptr(steps), _ptr(consts), steps.numel(), tick_mask, float(lr), BETA1, BETA2,
+            self._s()), 'ttl_sac_losses')
+
+    def thin_backward(self, d_out, a, w, n_out, block_diagonal, r0, r1, dz, part):
+        n_rows = a.shape[0]
+        n_in = a.shape[1] // n_out if block_diagonal else a.shape[1]
+        assert a.stride(1) == 1 and dz.stride(1) == 1 and d_out.stride(1) == 1
+        _lib.check(self.lib.ttl_thin_backward(
+            _ptr(d_out), d_out.stride(0), _ptr(a), a.stride(0), _ptr(w), n_rows, n_in, n_out,
+            int(block_diagonal), r0, r1, _rows_per_block(n_rows), _ptr(dz), dz.stride(0),
+            _ptr(part), part.stride(0), self._s()), 'ttl_thin_backward')
+
+    def relu_backward_bias(self, dz, a, r0, r1, part):
+        n_rows, n_cols = dz.shape
+        assert a.shape == dz.shape and a.stride(1) == 1 and dz.stride(1) == 1
+        _lib.check(self.lib.ttl_relu_backward_bias(
+            _ptr(dz), dz.stride(0), _ptr(a), a.stride(0), n_rows, n_cols, r0, r1,
+            _rows_per_block(n_rows), _ptr(part), part.stride(0), self._s()),
+            'ttl_relu_backward_bias')
+
+    def colsum_finalize(self, segs):
+        """segs: list of (part [R x ld] tensor, column offset, n, out tensor, scale)."""
+        arr = (_lib.ColsumSeg * len(segs))()
+        for k, (part, off, n, out, scale) in enumerate(segs):
+            assert out.numel() >= n and out.is_contiguous() and off + n <= part.shape[1]
+            arr[k].part = part.data_ptr() + 4 * off
+            arr[k].ld = part.stride(0)
+            arr[k].n_part = part.shape[0]
+            arr[k].n = n
+            arr[k].out = out.data_ptr()
+            arr[k].scale = scale
+            arr[k].accumulate = 0
+        _lib.check(self.lib.ttl_colsum_finalize(arr, len(segs), self._s()),
+                   'ttl_colsum_finalize')
+
+    def actor_head_backward(self, dh, h, wa, n_act, pi, ld_pi, eps, ls_raw, log_alpha,
+                            alpha_const, d_head):
+        n_rows, n_cols = dh.shape
+        assert h.shape == dh.shape and wa.is_contiguous() and wa.shape == (n_act, n_cols)
+        _lib.check(self.lib.ttl_sac_actor_head_backward(
+            _ptr(dh), dh.stride(0), _ptr(h), h.stride(0), _ptr(wa), n_rows, n_cols, n_act,
+            _ptr(pi), ld_pi, _ptr(eps), _ptr(ls_raw),
+            _ptr(log_alpha) if log_alpha is not None else None, float(alpha_const),
+            _ptr(d_head), self._s()), 'ttl_sac_actor_head_backward')
+
+    def adam_polyak(self, p, g, m, v, target, consts, tau):
+        _lib.check(self.lib.ttl_adam_polyak(
+            _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(target) if target is not None else None,
+            p.numel(), _ptr(consts), BETA1, BETA2, ADAM_EPS, float(tau), self._s()),
+            'ttl_adam_polyak')
+
+    def alpha_step(self, log_alpha, grad, m, v, mean_logp, target_entropy, consts):
+        _lib.check(self.lib.ttl_sac_alpha_step(
+            _ptr(log_alpha), _ptr(grad), _ptr(m), _ptr(v), _ptr(mean_logp),
+            float(target_entropy), _ptr(consts), BETA1, BETA2, ADAM_EPS, self._s()),
+            'ttl_sac_alpha_step')
+
+    def build_inputs(self, state, action, next_state, xs, n_state, n_act, w1, wa):
+        n = state.shape[0]
+        assert state.stride(1) == 1 and action.stride(1) == 1 and next_state.stride(1) == 1
+        _lib.check(self.lib.ttl_build_learner_inputs(
+            _ptr(state), state.stride(0), _ptr(action), action.stride(0), _ptr(next_state),
+            next_state.stride(0), n, n_state, n_act, _ptr(xs), xs.stride(0), _ptr(w1),
+            w1.stride(0), w1.shape[0], _ptr(wa), self._s()), 'ttl_build_learner_inputs')
+
+
+def _linears(seq):
+    """The Linear layers of a make_fc_network stack (Linear/ReLU ... Linear)."""
+    mods = list(seq)
+    lin = [m for m in mods if isinstance(m, nn.Linear)]
+    ok = all(isinstance(m, (nn.Linear, nn.ReLU)) for m in mods) and \
+        len(mods) == 2 * len(lin) - 1 and all(m.bias is not None for m in lin) and \
+        all(type(mods[2 * i + 1]) is nn.ReLU for i in range(len(lin) - 1))
+    return lin if ok and len(lin) >= 2 else None
+
+
+class _Arena:
+    """Flat fp32 storage of one network (actor, or the two critics interleaved)
+    in five copies -- online, target, gradient, Adam m, Adam v -- with views
+    per tensor.  ``slots``: [(name, shape)] in arena order; every slot starts
+    on a 16-byte boundary (the pads stay zero through Adam)."""
+
+    def __init__(self, slots, device, dtype=torch.float32):
+        self.offsets, off = {}, 0
+        for name, shape in slots:
+            n = 1
+            for d in shape:
+                n *= d
+            self.offsets[name] = (off, tuple(shape))
+            off += (n + 3) // 4 * 4
+        self.n = off
+        z = dict(dtype=dtype, device=device)
+        self.online = torch.zeros(off, **z)
+        self.target = torch.zeros(off, **z)
+        self.grad = torch.zeros(off, **z)
+        self.m = torch.zeros(off, **z)
+        self.v = torch.zeros(off, **z)
+
+    def view(self, flat, name):
+        off, shape = self.offsets[name]
+        n = 1
+        for d in shape:
+            n *= d
+        return flat[off:off + n].view(shape)
+
+
+class FusedSACUpdate:
+    """One SAC / SACAuto update on ``alg``'s networks (see the module
+    docstring).  ``alg`` is a ``tracktolearn_amd.algorithms.sac.SAC`` (or
+    ``SACAuto``); the parameters of ``alg.agent`` / ``alg.target`` and the
+    state of its optimizers are re-homed into the arenas on construction."""
+
+    def __init__(self, alg, ops=None):
+        self.alg = alg
+        self.device = torch.device(alg.device)
+        self.ops = ops if ops is not None else HipOps(self.device)
+        actor, critic = alg.agent.actor, alg.agent.critic
+        self.a_lin = _linears(actor.layers)
+        self.q_lin = [_linears(critic.q1), _linears(critic.q2)]
+        self.ta_lin = _linears(alg.target.actor.layers)
+        self.tq_lin = [_linears(alg.target.critic.q1), _linears(alg.target.critic.q2)]
+        if self.a_lin is None or None in self.q_lin:
+            raise ValueError('FusedSACUpdate needs Linear/ReLU stacks (make_fc_network)')
+        self.S = self.a_lin[0].in_features
+        self.A = alg.agent.actor.action_dim
+        self.L = len(self.a_lin) - 1                         # hidden layers
+        self.ha = [lin.out_features for lin in self.a_lin[:-1]]
+        self.hq = [lin.out_features for lin in self.q_lin[0][:-1]]
+        ok = len(self.q_lin[0]) == len(self.q_lin[1]) == self.L + 1 and \
+            self.a_lin[-1].out_features == 2 * self.A and self.A <= 4 and \
+            self.q_lin[0][0].in_features == self.S + self.A and \
+            all(a.weight.shape == b.weight.shape for a, b in zip(*self.q_lin)) and \
+            self.q_lin[0][-1].out_features == 1
+        if not ok:
+            raise ValueError('FusedSACUpdate: unsupported network shapes')
+        #: float32 on the GPU; the CPU schedule test also runs it in float64
+        self.dtype = self.a_lin[0].weight.dtype
+        if isinstance(self.ops, HipOps) and self.dtype != torch.float32:
+            raise ValueError('FusedSACUpdate: the HIP kernels are float32')
+        self.auto = hasattr(alg, 'log_alpha')
+        self._build_arenas()
+        self._batch = None
+        self.steps = torch.zeros(3, dtype=self.dtype, device=self.device)
+        self.consts = torch.zeros(6, dtype=self.dtype, device=self.device)
+        self._bind_optimizers()
+        self.loss_out = torch.zeros(8, dtype=self.dtype, device=self.device)
+        self.mean_logp = torch.zeros(1, dtype=self.dtype, device=self.device)
+
+    # ------------------------------------------------------------------ #
+    # arenas
+    def _build_arenas(self):
+        dev = self.device
+        a_slots = []
+        for l, lin in enumerate(self.a_lin):
+            a_slots += [(f'w{l}', lin.weight.shape), (f'b{l}', lin.bias.shape)]
+        self.arena_a = _Arena(a_slots, dev, self.dtype)
+        q_slots = []
+        for l, lin in enumerate(self.q_lin[0]):
+            o, i = lin.weight.shape
+            q_slots += [(f'w{l}', (2, o, i)), (f'b{l}', (2, o))]
+        self.arena_q = _Arena(q_slots, dev, self.dtype)
+        self._home(self.arena_a, 'online', [self.a_lin])
+        self._home(self.arena_a, 'target', [self.ta_lin])
+        self._home(self.arena_q, 'online', self.q_lin)
+        self._home(self.arena_q, 'target', self.tq_lin)
+
+    def _home(self, arena, which, nets):
+        """Move the parameters of ``nets`` (one list of Linears per network)
+        into ``arena.<which>`` and make them views of it; online parameters
+        get their ``.grad`` as a view of ``arena.grad``."""
+        flat = getattr(arena, which)
+        for k, lins in enumerate(nets):
+            for l, lin in enumerate(lins):
+                for name, p in ((f'w{l}', lin.weight), (f'b{l}', lin.bias)):
+                    v = arena.view(flat, name)
+                    v = v[k] if len(nets) > 1 else v
+                    v.copy_(p.data)
+                    p.data = v
+                    if which == 'online':
+                        g = arena.view(arena.grad, name)
+                        p.grad = g[k] if len(nets) > 1 else g
+
+    def _homed(self):
+        """Whether the parameters still are views of the arenas (``.to()`` /
+        ``.float()`` on a module re-allocates them)."""
+        a, q = self.arena_a, self.arena_q
+        return (self.a_lin[0].weight.data_ptr() == a.view(a.online, 'w0').data_ptr() and
+                self.q_lin[1][-1].bias.data_ptr() == q.view(q.online, f'b{self.L}')[1].data_ptr()
+                and self.ta_lin[0].weight.data_ptr() == a.view(a.target, 'w0').data_ptr() and
+                self.tq_lin[1][-1].bias.data_ptr() ==
+                q.view(q.target, f'b{self.L}')[1].data_ptr())
+
+    def _rehome(self):
+        self._home(self.arena_a, 'online', [self.a_lin])
+        self._home(self.arena_a, 'target', [self.ta_lin])
+        self._home(self.arena_q, 'online', self.q_lin)
+        self._home(self.arena_q, 'target', self.tq_lin)
+
+    def _attach_grads(self):
+        """``optimizer.zero_grad()`` (set_to_none) detaches ``.grad``."""
+        for arena, nets in ((self.arena_a, [self.a_lin]), (self.arena_q, self.q_lin)):
+            for k, lins in enumerate(nets):
+                for l, lin in enumerate(lins):
+                    for name, p in ((f'w{l}', lin.weight), (f'b{l}', lin.bias)):
+                        if p.grad is None or p.grad.data_ptr() == 0:
+                            g = arena.view(arena.grad, name)
+                            p.grad = g[k] if len(nets) > 1 else g
+
+    # ------------------------------------------------------------------ #
+    # optimizer state as views of the arenas
+    def _bind_optimizers(self):
+        alg = self.alg
+        table = [(alg.actor_optimizer, self.arena_a, [self.a_lin], 1),
+                 (alg.critic_optimizer, self.arena_q, self.q_lin, 2)]
+        for opt, arena, nets, k_opt in table:
+            for k, lins in enumerate(nets):
+                for l, lin in enumerate(lins):
+                    for name, p in ((f'w{l}', lin.weight), (f'b{l}', lin.bias)):
+                        self._bind_state(opt, p, k_opt,
+                                         *(arena.view(f, name)[k] if len(nets) > 1
+                                           else arena.view(f, name) for f in (arena.m, arena.v)))
+        if self.auto:
+            self.alpha_m = torch.zeros(1, dtype=self.dtype, device=self.device)
+            self.alpha_v = torch.zeros(1, dtype=self.dtype, device=self.device)
+            self._bind_state(alg.alpha_optimizer, alg.log_alpha, 0, self.alpha_m, self.alpha_v)
+            if alg.log_alpha.grad is None:
+                alg.log_alpha.grad = torch.zeros_like(alg.log_alpha)
+
+    def _bind_state(self, opt, p, k_opt, m_view, v_view):
+        st = opt.state[p]
+        if 'exp_avg' in st and st['exp_avg'].data_ptr() != m_view.data_ptr():
+            # state made by torch's own step() or load_state_dict(): import it
+            m_view.copy_(st['exp_avg'])
+            v_view.copy_(st['exp_avg_sq'])
+            self.steps[k_opt] = float(st['step'])
+        st['step'] = self.steps[k_opt]
+        st['exp_avg'] = m_view
+        st['exp_avg_sq'] = v_view
+
+    def _optimizers_bound(self):
+        alg = self.alg
+        a, q = self.arena_a, self.arena_q
+        st_a = alg.actor_optimizer.state.get(self.a_lin[0].weight, {})
+        st_q = alg.critic_optimizer.state.get(self.q_lin[1][-1].bias, {})
+        ok = ('exp_avg' in st_a and st_a['exp_avg'].data_ptr() == a.view(a.m, 'w0').data_ptr()
+              and 'exp_avg' in st_q and
+              st_q['exp_avg'].data_ptr() == q.view(q.m, f'b{self.L}')[1].data_ptr())
+        if ok and self.auto:
+            st = alg.alpha_optimizer.state.get(alg.log_alpha, {})
+            ok = 'exp_avg' in st and st['exp_avg'].data_ptr() == self.alpha_m.data_ptr()
+        return ok
+
+    # ------------------------------------------------------------------ #
+    # workspaces of a batch size
+    def _alloc(self, B):
+        dev, S, A, L = self.device, self.S, self.A, self.L
+        z = dict(dtype=self.dtype, device=dev)
+        ld = (S + A + 3) // 4 * 4
+        self.B, self.ld = B, ld
+        self.xs = torch.zeros(3 * B, ld, **z)
+        self.eps = torch.zeros(2 * B, A, **z)
+        self.act_a = [torch.empty(2 * B, h, **z) for h in self.ha]
+        self.logp = torch.empty(2 * B, **z)
+        self.ls_raw = torch.empty(2 * B, A, **z)
+        self.ent_part = torch.zeros(-(-2 * B // THIN_FWD_ROWS), 1, **z)
+        self.hc = [torch.empty(2 * B, 2 * h, **z) for h in self.hq]
+        self.ht = [torch.empty(B, 2 * h, **z) for h in self.hq]
+        self.q_on = torch.empty(2 * B, 2, **z)
+        self.q_tg = torch.empty(B, 2, **z)
+        self.dq = torch.empty(2 * B, 2, **z)
+        self.loss_part = torch.zeros(-(-B // LOSS_BLOCK), 8, **z)
+        self.dzc = [torch.empty(2 * B, 2 * h, **z) for h in self.hq]
+        self.dza = [torch.empty(B, h, **z) for h in self.ha]
+        self.wa = torch.empty(A, 2 * self.hq[0], **z)
+        self.d_head = torch.empty(B, 2 * A, **z)
+        R2, R1 = -(-2 * B // _rows_per_block(2 * B)), -(-B // _rows_per_block(B))
+        hqL, haL = self.hq[-1], self.ha[-1]
+        # slabs: [db below | dW thin | db thin] of the thin layers, [db] of the others
+        self.part_q_top = torch.zeros(R2, 2 * hqL + 2 * hqL + 2, **z)
+        self.part_a_top = torch.zeros(R1, haL + 2 * A * haL + 2 * A, **z)
+        # lower critic layers: rows [0,B) of the slab are the critic-loss rows;
+        # layer 0 runs the ReLU backward on those B rows only
+        self.part_q = [torch.zeros(R1 if l == 0 else R2, 2 * h, **z)
+                       for l, h in enumerate(self.hq[:-1])]
+        self.part_a = [torch.zeros(R1, h, **z) for h in self.ha[:-1]]
+
+    # ------------------------------------------------------------------ #
+    def update(self, batch, eps_pi=None, eps_next=None, want_losses=False):
+        """One update from ``batch`` = (state, action, next_state, reward,
+        not_done).  ``eps_*``: the N(0, 1) draws of the two policy samples
+        (drawn here, in the reference's order, when None)."""
+        alg, ops = self.alg, self.ops
+        state, action, next_state, reward, not_done = batch
+        B = state.shape[0]
+        if self._batch != B:
+            self._alloc(B)
+            self._batch = B
+        if not self._homed():
+            self._rehome()
+        if not self._optimizers_bound():
+            self._bind_optimizers()
+        self._attach_grads()
+        S, A, L, ld = self.S, self.A, self.L, self.ld
+        aa, aq = self.arena_a, self.arena_q
+        W = lambda arena, flat, l: arena.view(flat, f'w{l}')      # noqa: E731
+        Bv = lambda arena, flat, l: arena.view(flat, f'b{l}')     # noqa: E731
+        fused = torch._addmm_activation
+
+        # ---- inputs
+        xs = self.xs
+        ops.build_inputs(state, action, next_state, xs, S, A,
+                         W(aq, aq.online, 0).view(2 * self.hq[0], S + A), self.wa)
+        if eps_pi is None:
+            torch.randn((B, A), out=self.eps[:B])
+        else:
+            self.eps[:B].copy_(eps_pi)
+        if eps_next is None:
+            torch.randn((B, A), out=self.eps[B:])
+        else:
+            self.eps[B:].copy_(eps_next)
+
+        # ---- actor on rows [B, 3B): pi(s) and pi(s')
+        x = xs[B:, :S]
+        for l in range(L):
+            fused(Bv(aa, aa.online, l), x, W(aa, aa.online, l).t(), use_gelu=False,
+                  out=self.act_a[l])
+            x = self.act_a[l]
+        ops.thin_forward(x, W(aa, aa.online, L), Bv(aa, aa.online, L), 2 * A, False, HEAD_SAC,
+                         xs[B:, S:], ld, eps=self.eps, entropy_rows=B, logp=self.logp,
+                         ls_raw=self.ls_raw, ent_part=self.ent_part)
+
+        # ---- critics: online on rows [0, 2B), target on rows [2B, 3B)
+        for flat, rows, hbuf, qout in ((aq.online, xs[:2 * B], self.hc, self.q_on),
+                                       (aq.target, xs[2 * B:], self.ht, self.q_tg)):
+            x = rows[:, :S + A]
+            h0 = self.hq[0]
+            fused(Bv(aq, flat, 0).view(2 * h0), x, W(aq, flat, 0).view(2 * h0, S + A).t(),
+                  use_gelu=False, out=hbuf[0])
+            for l in range(1, L):
+                hp, h = self.hq[l - 1], self.hq[l]
+                for k in range(2):
+                    fused(Bv(aq, flat, l)[k], hbuf[l - 1][:, k * hp:(k + 1) * hp],
+                          W(aq, flat, l)[k].t(), use_gelu=False,
+                          out=hbuf[l][:, k * h:(k + 1) * h])
+            ops.thin_forward(hbuf[L - 1], W(aq, flat, L), Bv(aq, flat, L).view(2), 2, True,
+                             HEAD_PLAIN, qout, 2)
+
+        # ---- per-row losses, d loss / d q, Adam step counters
+        log_alpha = alg.log_alpha if self.auto else None
+        ops.sac_losses(self.q_on, self.q_tg, self.logp, reward, not_done, log_alpha,
+                       0.0 if self.auto else alg.alpha, alg.gamma, self.dq,
+                       self.loss_part if want_losses else None, self.steps, self.consts,
+                       0b111 if self.auto else 0b110, alg.lr)
+
+        # ---- critics backward: rows [0,B) train the critics, rows [B,2B)
+        #      carry the actor loss down to pi(s)
+        ops.thin_backward(self.dq, self.hc[L - 1], W(aq, aq.online, L), 2, True, 0, B,
+                          self.dzc[L - 1], self.part_q_top)
+        for l in range(L - 1, 0, -1):
+            hp, h = self.hq[l - 1], self.hq[l]
+            for k in range(2):
+                dz = self.dzc[l][:, k * h:(k + 1) * h]
+                torch.mm(dz[:B].t(), self.hc[l - 1][:B, k * hp:(k + 1) * hp],
+                         out=W(aq, aq.grad, l)[k])
+                torch.mm(dz, W(aq, aq.online, l)[k], out=self.dzc[l - 1][:, k * hp:(k + 1) * hp])
+            if l - 1 == 0:
+                ops.relu_backward_bias(self.dzc[0][:B], self.hc[0][:B], 0, B, self.part_q[0])
+            else:
+                ops.relu_backward_bias(self.dzc[l - 1], self.hc[l - 1], 0, B,
+                                       self.part_q[l - 1])
+        h0 = self.hq[0]
+        torch.mm(self.dzc[0][:B].t(), xs[:B, :S + A],
+                 out=W(aq, aq.grad, 0).view(2 * h0, S + A))
+        ops.actor_head_backward(self.dzc[0][B:], self.hc[0][B:], self.wa, A, xs[B:2 * B, S:],
+                                ld, self.eps, self.ls_raw, log_alpha,
+                                0.0 if self.auto else alg.alpha, self.d_head)
+
+        # ---- actor backward (rows [0,B) of its batch = pi(s))
+        ops.thin_backward(self.d_head, self.act_a[L - 1][:B], W(aa, aa.online, L), 2 * A, False,
+                          0, B, self.dza[L - 1], self.part_a_top)
+        for l in range(L - 1, 0, -1):
+            torch.mm(self.dza[l].t(), self.act_a[l - 1][:B], out=W(aa, aa.grad, l))
+            torch.mm(self.dza[l], W(aa, aa.online, l), out=self.dza[l - 1])
+            ops.relu_backward_bias(self.dza[l - 1], self.act_a[l - 1][:B], 0, B,
+                                   self.part_a[l - 1])
+        torch.mm(self.dza[0].t(), xs[B:2 * B, :S], out=W(aa, aa.grad, 0))
+
+        # ---- slabs -> gradients (fixed order)
+        haL, hqL = self.ha[-1], self.hq[-1]
+        segs = [(self.part_a_top, 0, haL, Bv(aa, aa.grad, L - 1), 1.0),
+                (self.part_a_top, haL, 2 * A * haL, W(aa, aa.grad, L).view(-1), 1.0),
+                (self.part_a_top, haL + 2 * A * haL, 2 * A, Bv(aa, aa.grad, L), 1.0)]
+        segs += [(self.part_a[l], 0, self.ha[l], Bv(aa, aa.grad, l), 1.0) for l in range(L - 1)]
+        segs.append((self.ent_part[:B // THIN_FWD_ROWS + (B % THIN_FWD_ROWS > 0)], 0, 1,
+                     self.mean_logp, 1.0 / B))
+        if want_losses:
+            segs.append((self.loss_part, 0, 8, self.loss_out, 1.0 / B))
+        ops.colsum_finalize(segs)
+        segs = [(self.part_q_top, 0, 2 * hqL, Bv(aq, aq.grad, L - 1).view(-1), 1.0),
+                (self.part_q_top, 2 * hqL, 2 * hqL, W(aq, aq.grad, L).view(-1), 1.0),
+                (self.part_q_top, 4 * hqL, 2, Bv(aq, aq.grad, L).view(-1), 1.0)]
+        segs += [(self.part_q[l], 0, 2 * self.hq[l], Bv(aq, aq.grad, l).view(-1), 1.0)
+                 for l in range(L - 1)]
+        ops.colsum_finalize(segs)
+
+        # ---- data-parallel replicas: one all-reduce per arena
+        if getattr(alg, '_dp', False):
+            self._all_reduce()
+
+        # ---- temperature, actor, critics: Adam (+ Polyak)
+        if self.auto:
+            ops.alpha_step(alg.log_alpha.data, alg.log_alpha.grad, self.alpha_m, self.alpha_v,
+                           self.mean_logp, alg.target_entropy, self.consts[0:2])
+        ops.adam_polyak(aa.online, aa.grad, aa.m, aa.v, aa.target, self.consts[2:4], alg.tau)
+        ops.adam_polyak(aq.online, aq.grad, aq.m, aq.v, aq.target, self.consts[4:6], alg.tau)
+        if want_losses:
+            lo = self.loss_out
+            return {'actor_loss': lo[0], 'critic_loss': lo[1] + lo[2], 'loss_q1': lo[1],
+                    'loss_q2': lo[2], 'Q1': lo[3], 'Q2': lo[4], 'backup': lo[5]}
+        return {}
+
+    def _all_reduce(self):
+        import torch.distributed as dist
+        group = self.alg._dp_group
+        world = dist.get_world_size(group)
+        for t in (self.arena_a.grad, self.arena_q.grad) + ((self.mean_logp,) if self.auto else ()):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            t /= world

@@ -1,0 +1,849 @@
+// ttl_learner.hip -- the learner kernels of libttl_hip.so (include/ttl_learner.h):
+// everything of one SAC / SACAuto update that is not a dense GEMM.
+//
+// Shapes: batch rows M = 4096..8192, hidden width 1024 per network, "thin"
+// layers of 1..6 units.  Every kernel here streams its matrices once (HBM /
+// Infinity-Cache bound, no reuse to tile for), 64-wide waves reading 1 KB of a
+// row per instruction (float4 per lane), four waves per workgroup taking
+// interleaved rows.  Column reductions (bias / thin-layer weight gradients) are
+// block partials in a slab + ttl_colsum_finalize: fixed summation order, no
+// float atomics, so a graph replay reproduces the eager update bit for bit.
+#include <cmath>
+
+#include "ttl_internal.h"
+#include "ttl_learner.h"
+
+namespace {
+
+constexpr int LB = 256;   // threads per workgroup
+constexpr int NW = 4;     // waves per workgroup
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;   // log(sqrt(2 pi))
+constexpr float LOG_2 = 0.69314718055994530942f;
+constexpr float LOG_STD_MIN = -20.f, LOG_STD_MAX = 2.f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+    // xor butterfly: every lane ends with the same bits (a + b == b + a)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int V>
+__device__ __forceinline__ void ldv(float (&x)[V], const float *p) {
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+    } else {
+        x[0] = *p;
+    }
+}
+template <int V>
+__device__ __forceinline__ void stv(float *p, const float (&x)[V]) {
+    if constexpr (V == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+        *p = x[0];
+    }
+}
+
+__device__ __forceinline__ float softplus_t(float x) {
+    // torch.nn.functional.softplus, beta 1, threshold 20
+    return x > 20.f ? x : log1pf(expf(x));
+}
+
+// ------------------------------------------------------------------------
+// thin forward (+ squashed-gaussian head)
+// ------------------------------------------------------------------------
+struct ThinFwd {
+    const float *a; int64_t lda;
+    const float *w; const float *b;
+    int n_rows, n_in;
+    int head; const float *eps; int ent_rows;
+    float *out; int64_t ld_out;
+    float *logp; float *ls_raw; float *ent_part;
+};
+
+constexpr int FWD_RW = 4;                       // rows per wave
+static_assert(FWD_RW * NW == TTL_THIN_FWD_ROWS, "block rows");
+
+template <int NOUT, bool BD, int V>
+__global__ __launch_bounds__(LB) void k_thin_forward(ThinFwd P) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * TTL_THIN_FWD_ROWS + wv * FWD_RW;
+    float acc[FWD_RW][NOUT];
+#pragma unroll
+    for (int r = 0; r < FWD_RW; ++r)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[r][o] = 0.f;
+    const float *arow[FWD_RW];
+#pragma unroll
+    for (int r = 0; r < FWD_RW; ++r) {
+        const int m = min(m0 + r, P.n_rows - 1);      // clamped: loads stay in bounds
+        arow[r] = P.a + (int64_t)m * P.lda;
+    }
+    if constexpr (!BD) {
+        for (int c = lane * V; c < P.n_in; c += 64 * V) {
+            float av[FWD_RW][V];
+#pragma unroll
+            for (int r = 0; r < FWD_RW; ++r) ldv<V>(av[r], arow[r] + c);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float wq[V];
+                ldv<V>(wq, P.w + (int64_t)o * P.n_in + c);
+#pragma unroll
+                for (int r = 0; r < FWD_RW; ++r)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[r][o] += av[r][v] * wq[v];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            for (int c = lane * V; c < P.n_in; c += 64 * V) {
+                float wq[V];
+                ldv<V>(wq, P.w + (int64_t)o * P.n_in + c);
+#pragma unroll
+                for (int r = 0; r < FWD_RW; ++r) {
+                    float av[V];
+                    ldv<V>(av, arow[r] + (int64_t)o * P.n_in + c);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[r][o] += av[v] * wq[v];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FWD_RW; ++r)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[r][o] = wave_sum(acc[r][o]) + P.b[o];
+
+    if (P.head != TTL_HEAD_SAC) {
+#pragma unroll
+        for (int r = 0; r < FWD_RW; ++r) {
+            const int m = m0 + r;
+            if (m < P.n_rows && lane == 0) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float y = acc[r][o];
+                    P.out[(int64_t)m * P.ld_out + o] = P.head == TTL_HEAD_TANH ? tanhf(y) : y;
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (NOUT % 2 == 0 && NOUT >= 2) {
+        constexpr int NA = NOUT / 2;
+        __shared__ float ent[NW];
+        float ent_wave = 0.f;
+#pragma unroll
+        for (int r = 0; r < FWD_RW; ++r) {
+            const int m = m0 + r;
+            const int mc = min(m, P.n_rows - 1);
+            float lg = 0.f, corr = 0.f, pi[NA], raw[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const float mu = acc[r][i];
+                raw[i] = acc[r][NA + i];
+                const float ls = fminf(fmaxf(raw[i], LOG_STD_MIN), LOG_STD_MAX);
+                const float sd = expf(ls);
+                const float u = mu + P.eps[(int64_t)mc * NA + i] * sd;
+                const float var = sd * sd;
+                const float d = u - mu;
+                const float g = -(d * d) / (2.f * var) - logf(sd) - HALF_LOG_2PI;
+                const float cr = 2.f * (LOG_2 - u - softplus_t(-2.f * u));
+                lg = i == 0 ? g : lg + g;
+                corr = i == 0 ? cr : corr + cr;
+                pi[i] = tanhf(u);
+            }
+            const float lp = lg - corr;
+            if (m < P.n_rows) {
+                if (m < P.ent_rows) ent_wave += lp;
+                if (lane == 0) {
+                    float *dst = P.out + (int64_t)m * P.ld_out;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        dst[i] = pi[i];
+                        P.ls_raw[(int64_t)m * NA + i] = raw[i];
+                    }
+                    P.logp[m] = lp;
+                }
+            }
+        }
+        if (P.ent_part) {
+            if (lane == 0) ent[wv] = ent_wave;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                P.ent_part[blockIdx.x] = ((ent[0] + ent[1]) + ent[2]) + ent[3];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// per-row loss terms, gradients w.r.t. the critic outputs, Adam step counters
+// ------------------------------------------------------------------------
+struct LossArgs {
+    const float *q_on, *q_tg, *logp, *reward, *not_done;
+    int n;
+    const float *log_alpha; float alpha_const, gamma;
+    float *dq, *loss_part;
+    float *steps, *consts; int n_opt; unsigned tick_mask;
+    double lr, beta1, beta2;
+};
+
+__global__ __launch_bounds__(LB) void k_sac_losses(LossArgs P) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    const float alpha = P.log_alpha ? expf(P.log_alpha[0]) : P.alpha_const;
+    const float inv_n = 1.f / (float)P.n;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < P.n) {
+        const float tq = fminf(P.q_tg[2 * i], P.q_tg[2 * i + 1]);
+        const float backup = P.reward[i] +
+                             (P.gamma * P.not_done[i]) * (tq - alpha * P.logp[P.n + i]);
+        const float q1 = P.q_on[2 * i], q2 = P.q_on[2 * i + 1];
+        const float e1 = q1 - backup, e2 = q2 - backup;
+        P.dq[2 * i] = 2.f * e1 * inv_n;
+        P.dq[2 * i + 1] = 2.f * e2 * inv_n;
+        const float p1 = P.q_on[2 * (P.n + i)], p2 = P.q_on[2 * (P.n + i) + 1];
+        // d(-min(p1, p2) / n): the smaller one takes it, a tie splits it
+        P.dq[2 * (P.n + i)] = p1 < p2 ? -inv_n : (p1 == p2 ? -0.5f * inv_n : 0.f);
+        P.dq[2 * (P.n + i) + 1] = p2 < p1 ? -inv_n : (p1 == p2 ? -0.5f * inv_n : 0.f);
+        s[0] = alpha * P.logp[i] - fminf(p1, p2);
+        s[1] = e1 * e1; s[2] = e2 * e2; s[3] = q1; s[4] = q2; s[5] = backup;
+    }
+    if (P.loss_part) {
+        __shared__ float red[NW][6];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float t = wave_sum(s[k]);
+            if (lane == 0) red[wv][k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int k = threadIdx.x;
+            P.loss_part[blockIdx.x * 8 + k] =
+                k < 6 ? ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k] : 0.f;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < P.n_opt; ++k) {
+            if (!((P.tick_mask >> k) & 1u)) continue;
+            const float st = P.steps[k] + 1.f;
+            P.steps[k] = st;
+            const double bc1 = 1.0 - pow(P.beta1, (double)st);
+            const double bc2 = 1.0 - pow(P.beta2, (double)st);
+            P.consts[2 * k] = (float)(P.lr / bc1);
+            P.consts[2 * k + 1] = (float)sqrt(bc2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// thin backward / ReLU backward with column partials
+// ------------------------------------------------------------------------
+struct ThinBwd {
+    const float *d_out; int64_t ld_dout;
+    const float *a; int64_t lda;
+    const float *w;
+    int n_rows, n_in, n_cols, r0, r1, rpb;
+    float *dz; int64_t ld_dz;
+    float *part; int64_t ld_part;
+};
+
+// sum the NW per-wave copies of NACC accumulator rows (64 * V columns each) in
+// wave order and write them to the slab row: accumulator k goes to
+// dst + off[k] + column
+template <int NACC, int V>
+__device__ __forceinline__ void block_reduce_store(float (*lds)[NACC][64 * V],
+                                                   const float (&acc)[NACC][V], float *dst,
+                                                   const int64_t (&off)[NACC], int col0,
+                                                   int n_cols) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v) lds[wv][k][lane * V + v] = acc[k][v];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NACC * 64 * V; e += LB) {
+        const int k = e / (64 * V), c = e - k * (64 * V);
+        if (col0 + c < n_cols)
+            dst[off[k] + col0 + c] =
+                ((lds[0][k][c] + lds[1][k][c]) + lds[2][k][c]) + lds[3][k][c];
+    }
+}
+
+template <int NOUT, bool BD, int V>
+__global__ __launch_bounds__(LB) void k_thin_backward(ThinBwd P) {
+    constexpr int NACC = BD ? 2 : 1 + NOUT;
+    __shared__ float lds[NW][NACC][64 * V];
+    __shared__ float dbo_s[NW][NOUT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col0 = blockIdx.x * 64 * V;
+    const int col = col0 + lane * V;
+    const bool cok = col < P.n_cols;
+    const int colc = cok ? col : 0;
+    const int ob = BD ? colc / P.n_in : 0;                 // my critic (block diagonal)
+    float wq[BD ? 1 : NOUT][V];
+    if constexpr (BD) {
+        ldv<V>(wq[0], P.w + colc);                         // [n_out][n_in] flat == column
+    } else {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) ldv<V>(wq[o], P.w + (int64_t)o * P.n_in + colc);
+    }
+    float acc[NACC][V];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[k][v] = 0.f;
+    float dbo[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) dbo[o] = 0.f;
+
+    const int mb = blockIdx.y * P.rpb;
+#pragma unroll 4
+    for (int i = wv; i < P.rpb; i += NW) {
+        const int m = mb + i;
+        if (m >= P.n_rows) break;
+        float d[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) d[o] = P.d_out[(int64_t)m * P.ld_dout + o];
+        float av[V], g[V];
+        ldv<V>(av, P.a + (int64_t)m * P.lda + colc);
+        float dsel = d[0];
+        if constexpr (BD) {
+#pragma unroll
+            for (int o = 1; o < NOUT; ++o) dsel = ob == o ? d[o] : dsel;
+#pragma unroll
+            for (int v = 0; v < V; ++v) g[v] = dsel * wq[0][v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float t = d[0] * wq[0][v];
+#pragma unroll
+                for (int o = 1; o < NOUT; ++o) t += d[o] * wq[o][v];
+                g[v] = t;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) g[v] = av[v] > 0.f ? g[v] : 0.f;
+        if (cok) stv<V>(P.dz + (int64_t)m * P.ld_dz + col, g);
+        if (m >= P.r0 && m < P.r1) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[0][v] += g[v];
+            if constexpr (BD) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[1][v] += dsel * av[v];
+            } else {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[1 + o][v] += d[o] * av[v];
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dbo[o] += d[o];
+        }
+    }
+    float *dst = P.part + (int64_t)blockIdx.y * P.ld_part;
+    int64_t off[NACC];
+    off[0] = 0;
+    if constexpr (BD) {
+        off[1] = P.n_cols;
+    } else {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) off[1 + o] = P.n_cols + (int64_t)o * P.n_in;
+    }
+    block_reduce_store<NACC, V>(lds, acc, dst, off, col0, P.n_cols);
+    if (blockIdx.x == 0) {
+        if (lane == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dbo_s[wv][o] = dbo[o];
+        }
+        __syncthreads();
+        if (threadIdx.x < NOUT) {
+            const int o = threadIdx.x;
+            dst[P.n_cols + (int64_t)NOUT * P.n_in + o] =
+                ((dbo_s[0][o] + dbo_s[1][o]) + dbo_s[2][o]) + dbo_s[3][o];
+        }
+    }
+}
+
+struct ReluBwd {
+    float *dz; int64_t ld_dz;
+    const float *a; int64_t lda;
+    int n_rows, n_cols, r0, r1, rpb;
+    float *part; int64_t ld_part;
+};
+
+template <int V>
+__global__ __launch_bounds__(LB) void k_relu_backward_bias(ReluBwd P) {
+    __shared__ float lds[NW][1][64 * V];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col0 = blockIdx.x * 64 * V;
+    const int col = col0 + lane * V;
+    const bool cok = col < P.n_cols;
+    const int colc = cok ? col : 0;
+    float acc[1][V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[0][v] = 0.f;
+    const int mb = blockIdx.y * P.rpb;
+#pragma unroll 4
+    for (int i = wv; i < P.rpb; i += NW) {
+        const int m = mb + i;
+        if (m >= P.n_rows) break;
+        float av[V], g[V];
+        ldv<V>(av, P.a + (int64_t)m * P.lda + colc);
+        ldv<V>(g, P.dz + (int64_t)m * P.ld_dz + colc);
+#pragma unroll
+        for (int v = 0; v < V; ++v) g[v] = av[v] > 0.f ? g[v] : 0.f;
+        if (m >= P.r0 && m < P.r1) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[0][v] += g[v];
+        }
+        if (cok) stv<V>(P.dz + (int64_t)m * P.ld_dz + col, g);
+    }
+    const int64_t off[1] = {0};
+    block_reduce_store<1, V>(lds, acc, P.part + (int64_t)blockIdx.y * P.ld_part, off, col0,
+                             P.n_cols);
+}
+
+// ------------------------------------------------------------------------
+// slab -> gradient
+// ------------------------------------------------------------------------
+struct Segs {
+    ttl_colsum_seg s[TTL_COLSUM_MAX_SEGS];
+    int first_block[TTL_COLSUM_MAX_SEGS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(LB) void k_colsum_finalize(Segs S) {
+    __shared__ float lds[LB];
+    int k = 0;
+    while (k + 1 < S.n && (int)blockIdx.x >= S.first_block[k + 1]) ++k;
+    const ttl_colsum_seg sg = S.s[k];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (sg.n > 8) {
+        const int col = (blockIdx.x - S.first_block[k]) * 64 + lane;
+        float acc = 0.f;
+        if (col < sg.n)
+            for (int r = wv; r < sg.n_part; r += NW) acc += sg.part[(int64_t)r * sg.ld + col];
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        if (wv == 0 && col < sg.n) {
+            float t = ((lds[lane] + lds[64 + lane]) + lds[128 + lane]) + lds[192 + lane];
+            t *= sg.scale;
+            if (sg.accumulate) t += sg.out[col];
+            sg.out[col] = t;
+        }
+        return;
+    }
+    // narrow segment (scalars: loss terms, thin-layer bias grads): the rows
+    // over the threads, a fixed tree over the block
+    for (int c = 0; c < sg.n; ++c) {
+        float acc = 0.f;
+        for (int r = threadIdx.x; r < sg.n_part; r += LB) acc += sg.part[(int64_t)r * sg.ld + c];
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        for (int h = LB / 2; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) lds[threadIdx.x] += lds[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float t = lds[0] * sg.scale;
+            if (sg.accumulate) t += sg.out[c];
+            sg.out[c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------
+// d(actor loss) / d(actor head outputs)
+// ------------------------------------------------------------------------
+struct HeadBwd {
+    const float *dh; int64_t ld_dh;
+    const float *h; int64_t ld_h;
+    const float *wa;                 // [n_act][n_cols]: action columns of the stacked W1
+    int n_rows, n_cols;
+    const float *pi; int64_t ld_pi;
+    const float *eps, *ls_raw, *log_alpha; float alpha_const;
+    float *d_head;
+};
+
+template <int NA, int V>
+__global__ __launch_bounds__(LB) void k_sac_actor_head_backward(HeadBwd P) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * (NW * FWD_RW) + wv * FWD_RW;
+    float acc[FWD_RW][NA];
+#pragma unroll
+    for (int r = 0; r < FWD_RW; ++r)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acc[r][i] = 0.f;
+    const float *hrow[FWD_RW], *drow[FWD_RW];
+#pragma unroll
+    for (int r = 0; r < FWD_RW; ++r) {
+        const int m = min(m0 + r, P.n_rows - 1);
+        hrow[r] = P.h + (int64_t)m * P.ld_h;
+        drow[r] = P.dh + (int64_t)m * P.ld_dh;
+    }
+    for (int c = lane * V; c < P.n_cols; c += 64 * V) {
+        float g[FWD_RW][V];
+#pragma unroll
+        for (int r = 0; r < FWD_RW; ++r) {
+            float hv[V];
+            ldv<V>(hv, hrow[r] + c);
+            ldv<V>(g[r], drow[r] + c);
+#pragma unroll
+            for (int v = 0; v < V; ++v) g[r][v] = hv[v] > 0.f ? g[r][v] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            float wq[V];
+            ldv<V>(wq, P.wa + (int64_t)i * P.n_cols + c);
+#pragma unroll
+            for (int r = 0; r < FWD_RW; ++r)
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc[r][i] += g[r][v] * wq[v];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FWD_RW; ++r)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acc[r][i] = wave_sum(acc[r][i]);
+    const float alpha = P.log_alpha ? expf(P.log_alpha[0]) : P.alpha_const;
+    const float an = alpha / (float)P.n_rows;
+#pragma unroll
+    for (int r = 0; r < FWD_RW; ++r) {
+        const int m = m0 + r;
+        if (m < P.n_rows && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const float t = P.pi[(int64_t)m * P.ld_pi + i];
+                const float du = an * (2.f * t) + acc[r][i] * (1.f - t * t);
+                const float raw = P.ls_raw[(int64_t)m * NA + i];
+                const bool in = raw >= LOG_STD_MIN && raw <= LOG_STD_MAX;
+                const float sd = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
+                P.d_head[(int64_t)m * 2 * NA + i] = du;
+                P.d_head[(int64_t)m * 2 * NA + NA + i] =
+                    in ? du * (P.eps[(int64_t)m * NA + i] * sd) - an : 0.f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------
+// Adam + Polyak over a flat arena
+// ------------------------------------------------------------------------
+struct AdamArgs {
+    float *p, *g, *m, *v, *t;
+    int64_t n;
+    const float *consts;
+    float b1, b2, eps, tau;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float *t,
+                                         const AdamArgs &A, float step_size, float bc2s,
+                                         float one_m_tau) {
+    m = m + (g - m) * (1.f - A.b1);                     // lerp_(grad, 1 - beta1)
+    v = v * A.b2 + ((1.f - A.b2) * g) * g;              // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(v) / bc2s + A.eps;
+    p = p + (-step_size) * (m / denom);                 // addcdiv_(m, denom, -step_size)
+    if (t) *t = *t * one_m_tau + p * A.tau;
+}
+
+__global__ __launch_bounds__(LB) void k_adam_polyak(AdamArgs A) {
+    const float step_size = A.consts[0], bc2s = A.consts[1];
+    const float one_m_tau = (float)(1.0 - (double)A.tau);
+    const int64_t i4 = ((int64_t)blockIdx.x * LB + threadIdx.x) * 4;
+    if (i4 + 3 < A.n) {
+        float p[4], g[4], m[4], v[4], t[4];
+        ldv<4>(p, A.p + i4); ldv<4>(g, A.g + i4); ldv<4>(m, A.m + i4); ldv<4>(v, A.v + i4);
+        if (A.t) ldv<4>(t, A.t + i4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            adam_one(p[k], g[k], m[k], v[k], A.t ? &t[k] : nullptr, A, step_size, bc2s, one_m_tau);
+        stv<4>(A.p + i4, p); stv<4>(A.m + i4, m); stv<4>(A.v + i4, v);
+        if (A.t) stv<4>(A.t + i4, t);
+    } else {
+        for (int64_t i = i4; i < A.n; ++i) {
+            float p = A.p[i], m = A.m[i], v = A.v[i], t = A.t ? A.t[i] : 0.f;
+            adam_one(p, A.g[i], m, v, A.t ? &t : nullptr, A, step_size, bc2s, one_m_tau);
+            A.p[i] = p; A.m[i] = m; A.v[i] = v;
+            if (A.t) A.t[i] = t;
+        }
+    }
+}
+
+struct AlphaArgs {
+    float *p, *g, *m, *v;
+    const float *mean_logp; float target_entropy;
+    const float *consts;
+    float b1, b2, eps;
+};
+
+__global__ void k_sac_alpha_step(AlphaArgs P) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float ml = P.mean_logp[0];
+    const float g = -(ml + P.target_entropy);
+    const float alpha_before = expf(P.p[0]);
+    AdamArgs A{P.p, P.g, P.m, P.v, nullptr, 1, P.consts, P.b1, P.b2, P.eps, 0.f};
+    float p = P.p[0], m = P.m[0], v = P.v[0];
+    adam_one(p, g, m, v, nullptr, A, P.consts[0], P.consts[1], 1.f);
+    P.p[0] = p; P.m[0] = m; P.v[0] = v;
+    P.g[0] = g + alpha_before * ml;
+}
+
+// ------------------------------------------------------------------------
+// network input rows
+// ------------------------------------------------------------------------
+struct BuildArgs {
+    const float *s; int64_t ld_s; const float *a; int64_t ld_a; const float *s2; int64_t ld_s2;
+    int n, n_state, n_act;
+    float *xs; int64_t ld;
+    const float *w1; int64_t ld_w1; int n_w1; float *wa;
+    int row_blocks;
+};
+
+__global__ __launch_bounds__(LB) void k_build_learner_inputs(BuildArgs P) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= P.row_blocks) {
+        // the action columns of the critics' first layer, transposed
+        const int j = (blockIdx.x - P.row_blocks) * LB + threadIdx.x;
+        if (j < P.n_w1)
+            for (int i = 0; i < P.n_act; ++i)
+                P.wa[(int64_t)i * P.n_w1 + j] = P.w1[(int64_t)j * P.ld_w1 + P.n_state + i];
+        return;
+    }
+    const int m = blockIdx.x * NW + wv;
+    if (m >= P.n) return;
+    const float *s = P.s + (int64_t)m * P.ld_s, *s2 = P.s2 + (int64_t)m * P.ld_s2;
+    float *a_row = P.xs + (int64_t)m * P.ld, *pi_row = P.xs + (int64_t)(P.n + m) * P.ld;
+    float *n_row = P.xs + (int64_t)(2 * P.n + m) * P.ld;
+    for (int c = lane; c < P.n_state; c += 64) {
+        const float x = s[c], y = s2[c];
+        a_row[c] = x;
+        pi_row[c] = x;
+        n_row[c] = y;
+    }
+    if (lane < P.n_act) a_row[P.n_state + lane] = P.a[(int64_t)m * P.ld_a + lane];
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+#define LAUNCH_CHECK(name)                                                       \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess)                                                    \
+            return fail(TTL_ERR_HIP, name ": %s", hipGetErrorString(e_));        \
+    } while (0)
+
+extern "C" {
+
+int ttl_thin_forward(const float *a, int64_t lda, const float *w, const float *b,
+                     int32_t n_rows, int32_t n_in, int32_t n_out, int32_t block_diagonal,
+                     int32_t head, const float *eps, int32_t entropy_rows, float *out,
+                     int64_t ld_out, float *logp, float *log_std_raw, float *entropy_part,
+                     void *hip_stream) {
+    if (!a || !w || !b || !out || n_rows <= 0 || n_in <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_thin_forward: null pointer or empty shape");
+    const int64_t width = block_diagonal ? (int64_t)n_out * n_in : n_in;
+    if (lda < width) return fail(TTL_ERR_INVALID, "ttl_thin_forward: lda %lld < %lld",
+                                 (long long)lda, (long long)width);
+    if (head == TTL_HEAD_SAC) {
+        if (block_diagonal || (n_out != 2 && n_out != 4 && n_out != 6 && n_out != 8))
+            return fail(TTL_ERR_INVALID, "ttl_thin_forward: SAC head needs a dense layer of "
+                                         "2, 4, 6 or 8 units (got %d)", n_out);
+        if (!eps || !logp || !log_std_raw || entropy_rows < 0 || entropy_rows > n_rows)
+            return fail(TTL_ERR_INVALID, "ttl_thin_forward: SAC head outputs missing");
+        if (ld_out < n_out / 2)
+            return fail(TTL_ERR_INVALID, "ttl_thin_forward: output stride too small");
+    } else if (head != TTL_HEAD_PLAIN && head != TTL_HEAD_TANH) {
+        return fail(TTL_ERR_INVALID, "ttl_thin_forward: unknown head %d", head);
+    } else if (ld_out < n_out) {
+        return fail(TTL_ERR_INVALID, "ttl_thin_forward: output stride too small");
+    }
+    ThinFwd P{a, lda, w, b, n_rows, n_in, head, eps, entropy_rows, out, ld_out,
+              logp, log_std_raw, head == TTL_HEAD_SAC ? entropy_part : nullptr};
+    const bool vec = n_in % 4 == 0 && lda % 4 == 0 && aligned16(a) && aligned16(w);
+    const dim3 grid((n_rows + TTL_THIN_FWD_ROWS - 1) / TTL_THIN_FWD_ROWS), block(LB);
+    hipStream_t s = S(hip_stream);
+#define FWD_CASE(N, BDV)                                                                  \
+    if (n_out == N && (block_diagonal != 0) == BDV) {                                     \
+        if (vec) k_thin_forward<N, BDV, 4><<<grid, block, 0, s>>>(P);                     \
+        else k_thin_forward<N, BDV, 1><<<grid, block, 0, s>>>(P);                         \
+        LAUNCH_CHECK("k_thin_forward");                                                   \
+        return TTL_OK;                                                                    \
+    }
+    FWD_CASE(1, false) FWD_CASE(2, false) FWD_CASE(3, false) FWD_CASE(4, false)
+    FWD_CASE(6, false) FWD_CASE(8, false) FWD_CASE(2, true) FWD_CASE(1, true)
+#undef FWD_CASE
+    return fail(TTL_ERR_UNSUPPORTED, "ttl_thin_forward: no kernel for n_out = %d (%s)", n_out,
+                block_diagonal ? "block diagonal" : "dense");
+}
+
+int ttl_sac_losses(const float *q_online, const float *q_target, const float *logp,
+                   const float *reward, const float *not_done, int32_t n,
+                   const float *log_alpha, float alpha_const, float gamma, float *dq,
+                   float *loss_part, float *steps, float *adam_consts, int32_t n_opt,
+                   uint32_t tick_mask, double lr, double beta1, double beta2,
+                   void *hip_stream) {
+    if (!q_online || !q_target || !logp || !reward || !not_done || !dq || n <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_sac_losses: null pointer or empty batch");
+    if (n_opt < 0 || n_opt > 8 || (n_opt && (!steps || !adam_consts)))
+        return fail(TTL_ERR_INVALID, "ttl_sac_losses: bad optimizer table");
+    LossArgs P{q_online, q_target, logp, reward, not_done, n, log_alpha, alpha_const, gamma,
+               dq, loss_part, steps, adam_consts, n_opt, tick_mask, lr, beta1, beta2};
+    k_sac_losses<<<dim3((n + LB - 1) / LB), dim3(LB), 0, S(hip_stream)>>>(P);
+    LAUNCH_CHECK("k_sac_losses");
+    return TTL_OK;
+}
+
+int ttl_thin_backward(const float *d_out, int64_t ld_dout, const float *a, int64_t lda,
+                      const float *w, int32_t n_rows, int32_t n_in, int32_t n_out,
+                      int32_t block_diagonal, int32_t r0, int32_t r1, int32_t rows_per_block,
+                      float *dz, int64_t ld_dz, float *part, int64_t ld_part,
+                      void *hip_stream) {
+    if (!d_out || !a || !w || !dz || !part || n_rows <= 0 || n_in <= 0 || rows_per_block <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_thin_backward: null pointer or empty shape");
+    if (a == dz) return fail(TTL_ERR_INVALID, "ttl_thin_backward: a and dz alias");
+    const int64_t n_cols = block_diagonal ? (int64_t)n_out * n_in : n_in;
+    if (lda < n_cols || ld_dz < n_cols || ld_dout < n_out ||
+        ld_part < n_cols + (int64_t)n_out * n_in + n_out)
+        return fail(TTL_ERR_INVALID, "ttl_thin_backward: a stride is too small");
+    ThinBwd P{d_out, ld_dout, a, lda, w, n_rows, n_in, (int)n_cols, r0, r1, rows_per_block,
+              dz, ld_dz, part, ld_part};
+    const bool vec = n_in % 4 == 0 && lda % 4 == 0 && ld_dz % 4 == 0 && aligned16(a) &&
+                     aligned16(dz) && aligned16(w);
+    const int V = vec ? 4 : 1;
+    const dim3 grid((unsigned)((n_cols + 64 * V - 1) / (64 * V)),
+                    (unsigned)((n_rows + rows_per_block - 1) / rows_per_block)), block(LB);
+    hipStream_t s = S(hip_stream);
+#define BWD_CASE(N, BDV)                                                                  \
+    if (n_out == N && (block_diagonal != 0) == BDV) {                                     \
+        if (vec) k_thin_backward<N, BDV, 4><<<grid, block, 0, s>>>(P);                    \
+        else k_thin_backward<N, BDV, 1><<<grid, block, 0, s>>>(P);                        \
+        LAUNCH_CHECK("k_thin_backward");                                                  \
+        return TTL_OK;                                                                    \
+    }
+    BWD_CASE(1, false) BWD_CASE(2, false) BWD_CASE(3, false) BWD_CASE(4, false)
+    BWD_CASE(6, false) BWD_CASE(8, false) BWD_CASE(2, true) BWD_CASE(1, true)
+#undef BWD_CASE
+    return fail(TTL_ERR_UNSUPPORTED, "ttl_thin_backward: no kernel for n_out = %d (%s)", n_out,
+                block_diagonal ? "block diagonal" : "dense");
+}
+
+int ttl_relu_backward_bias(float *dz, int64_t ld_dz, const float *a, int64_t lda,
+                           int32_t n_rows, int32_t n_cols, int32_t r0, int32_t r1,
+                           int32_t rows_per_block, float *part, int64_t ld_part,
+                           void *hip_stream) {
+    if (!dz || !a || !part || n_rows <= 0 || n_cols <= 0 || rows_per_block <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_relu_backward_bias: null pointer or empty shape");
+    if (ld_dz < n_cols || lda < n_cols || ld_part < n_cols)
+        return fail(TTL_ERR_INVALID, "ttl_relu_backward_bias: a stride is too small");
+    ReluBwd P{dz, ld_dz, a, lda, n_rows, n_cols, r0, r1, rows_per_block, part, ld_part};
+    const bool vec = n_cols % 4 == 0 && lda % 4 == 0 && ld_dz % 4 == 0 && aligned16(a) &&
+                     aligned16(dz);
+    const int V = vec ? 4 : 1;
+    const dim3 grid((unsigned)((n_cols + 64 * V - 1) / (64 * V)),
+                    (unsigned)((n_rows + rows_per_block - 1) / rows_per_block)), block(LB);
+    if (vec) k_relu_backward_bias<4><<<grid, block, 0, S(hip_stream)>>>(P);
+    else k_relu_backward_bias<1><<<grid, block, 0, S(hip_stream)>>>(P);
+    LAUNCH_CHECK("k_relu_backward_bias");
+    return TTL_OK;
+}
+
+int ttl_colsum_finalize(const ttl_colsum_seg *segs, int32_t n_segs, void *hip_stream) {
+    if (!segs || n_segs <= 0 || n_segs > TTL_COLSUM_MAX_SEGS)
+        return fail(TTL_ERR_INVALID, "ttl_colsum_finalize: 1..%d segments", TTL_COLSUM_MAX_SEGS);
+    Segs Sg;
+    int blocks = 0;
+    for (int k = 0; k < n_segs; ++k) {
+        const ttl_colsum_seg &g = segs[k];
+        if (!g.part || !g.out || g.n <= 0 || g.n_part <= 0 || g.ld < g.n)
+            return fail(TTL_ERR_INVALID, "ttl_colsum_finalize: segment %d is malformed", k);
+        Sg.s[k] = g;
+        Sg.first_block[k] = blocks;
+        blocks += g.n > 8 ? (g.n + 63) / 64 : 1;
+    }
+    Sg.first_block[n_segs] = blocks;
+    Sg.n = n_segs;
+    k_colsum_finalize<<<dim3(blocks), dim3(LB), 0, S(hip_stream)>>>(Sg);
+    LAUNCH_CHECK("k_colsum_finalize");
+    return TTL_OK;
+}
+
+int ttl_sac_actor_head_backward(const float *dh, int64_t ld_dh, const float *h, int64_t ld_h,
+                                const float *wa, int32_t n_rows, int32_t n_cols, int32_t n_act,
+                                const float *pi, int64_t ld_pi, const float *eps,
+                                const float *log_std_raw, const float *log_alpha,
+                                float alpha_const, float *d_head, void *hip_stream) {
+    if (!dh || !h || !wa || !pi || !eps || !log_std_raw || !d_head || n_rows <= 0 || n_cols <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_sac_actor_head_backward: null pointer or empty shape");
+    if (ld_dh < n_cols || ld_h < n_cols || ld_pi < n_act)
+        return fail(TTL_ERR_INVALID, "ttl_sac_actor_head_backward: a stride is too small");
+    HeadBwd P{dh, ld_dh, h, ld_h, wa, n_rows, n_cols, pi, ld_pi, eps, log_std_raw, log_alpha,
+              alpha_const, d_head};
+    const bool vec = n_cols % 4 == 0 && ld_dh % 4 == 0 && ld_h % 4 == 0 && aligned16(dh) &&
+                     aligned16(h) && aligned16(wa);
+    const dim3 grid((n_rows + NW * FWD_RW - 1) / (NW * FWD_RW)), block(LB);
+    hipStream_t s = S(hip_stream);
+#define HB_CASE(N)                                                                        \
+    if (n_act == N) {                                                                     \
+        if (vec) k_sac_actor_head_backward<N, 4><<<grid, block, 0, s>>>(P);               \
+        else k_sac_actor_head_backward<N, 1><<<grid, block, 0, s>>>(P);                   \
+        LAUNCH_CHECK("k_sac_actor_head_backward");                                        \
+        return TTL_OK;                                                                    \
+    }
+    HB_CASE(1) HB_CASE(2) HB_CASE(3) HB_CASE(4)
+#undef HB_CASE
+    return fail(TTL_ERR_UNSUPPORTED, "ttl_sac_actor_head_backward: n_act = %d", n_act);
+}
+
+int ttl_adam_polyak(float *p, float *g, float *m, float *v, float *target, int64_t n,
+                    const float *consts, float beta1, float beta2, float eps, float tau,
+                    void *hip_stream) {
+    if (!p || !g || !m || !v || !consts || n <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_adam_polyak: null pointer or empty arena");
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) ||
+        (target && !aligned16(target)))
+        return fail(TTL_ERR_INVALID, "ttl_adam_polyak: arenas must be 16-byte aligned");
+    AdamArgs A{p, g, m, v, target, n, consts, beta1, beta2, eps, tau};
+    const int64_t threads = (n + 3) / 4;
+    k_adam_polyak<<<dim3((unsigned)((threads + LB - 1) / LB)), dim3(LB), 0, S(hip_stream)>>>(A);
+    LAUNCH_CHECK("k_adam_polyak");
+    return TTL_OK;
+}
+
+int ttl_sac_alpha_step(float *log_alpha, float *grad, float *m, float *v,
+                       const float *mean_logp, float target_entropy, const float *consts,
+                       float beta1, float beta2, float eps, void *hip_stream) {
+    if (!log_alpha || !grad || !m || !v || !mean_logp || !consts)
+        return fail(TTL_ERR_INVALID, "ttl_sac_alpha_step: null pointer");
+    AlphaArgs P{log_alpha, grad, m, v, mean_logp, target_entropy, consts, beta1, beta2, eps};
+    k_sac_alpha_step<<<dim3(1), dim3(64), 0, S(hip_stream)>>>(P);
+    LAUNCH_CHECK("k_sac_alpha_step");
+    return TTL_OK;
+}
+
+int ttl_build_learner_inputs(const float *state, int64_t ld_s, const float *action, int64_t ld_a,
+                             const float *next_state, int64_t ld_s2, int32_t n, int32_t n_state,
+                             int32_t n_act, float *xs, int64_t ld, const float *w1,
+                             int64_t ld_w1, int32_t n_w1_rows, float *wa, void *hip_stream) {
+    if (!state || !action || !next_state || !xs || n <= 0 || n_state <= 0 || n_act <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_build_learner_inputs: null pointer or empty shape");
+    if (ld_s < n_state || ld_s2 < n_state || ld_a < n_act || ld < n_state + n_act || n_act > 64)
+        return fail(TTL_ERR_INVALID, "ttl_build_learner_inputs: a stride is too small");
+    if (w1 && (!wa || n_w1_rows <= 0 || ld_w1 < n_state + n_act))
+        return fail(TTL_ERR_INVALID, "ttl_build_learner_inputs: bad first-layer weights");
+    const int row_blocks = (n + NW - 1) / NW;
+    const int w_blocks = w1 ? (n_w1_rows + LB - 1) / LB : 0;
+    BuildArgs P{state, ld_s, action, ld_a, next_state, ld_s2, n, n_state, n_act, xs, ld,
+                w1, ld_w1, w1 ? n_w1_rows : 0, wa, row_blocks};
+    k_build_learner_inputs<<<dim3(row_blocks + w_blocks), dim3(LB), 0, S(hip_stream)>>>(P);
+    LAUNCH_CHECK("k_build_learner_inputs");
+    return TTL_OK;
+}
+
+}  // extern "C"
