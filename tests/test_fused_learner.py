@@ -163,6 +163,16 @@ def _close(a, b, rtol, atol, what):
     assert bool((err <= tol).all()), (what, float(err.max()), float((err / tol).max()))
 
 
+def _no_worse(hip, ref32, ref64, what, factor=4.0, atol=1e-7):
+    """|hip - float64| <= factor * |torch float32 restatement - float64| + atol,
+    in the max norm: the kernel is as accurate as the same formula through
+    torch's own float32 kernels (whose GEMM sums in another order)."""
+    hip, ref32, ref64 = (t.detach().double().cpu() for t in (hip, ref32, ref64))
+    e_hip, e_32 = float((hip - ref64).abs().max()), float((ref32 - ref64).abs().max())
+    assert e_hip <= factor * e_32 + atol * max(1.0, float(ref64.abs().max())), \
+        (what, e_hip, e_32)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,H,A', [(8192, 1024, 3), (4096, 1024, 3), (100, 68, 2), (37, 45, 3),
                                    (16, 2050, 4), (5, 7, 1)])
@@ -171,7 +181,6 @@ def test_thin_forward_kernels(M, H, A):
                                                           THIN_FWD_ROWS, HipOps)
     hip, ref = HipOps(DEV), TorchOps()
     g = torch.Generator().manual_seed(M + H)
-    z = dict(device=DEV)
     # strided rows (ld > H) as the side-by-side critic activations have
     a = torch.randn(M, H + 8, generator=g).to(DEV)[:, :H]
     w = (torch.randn(2 * A, H, generator=g) / H ** 0.5).to(DEV)
@@ -181,89 +190,101 @@ def test_thin_forward_kernels(M, H, A):
     eps = torch.randn(M, A, generator=g).to(DEV)
     ent_rows = M // 2 + 3
     outs = []
-    for ops in (hip, ref):
+    for ops, dt in ((hip, torch.float32), (ref, torch.float32), (ref, torch.float64)):
+        z = dict(device=DEV, dtype=dt)
         out = torch.zeros(M, A + 5, **z)
         logp, raw = torch.zeros(M, **z), torch.zeros(M, A, **z)
         part = torch.zeros(-(-M // THIN_FWD_ROWS), 1, **z)
-        ops.thin_forward(a, w, b, 2 * A, False, HEAD_SAC, out[:, 2:], A + 5, eps=eps,
-                         entropy_rows=ent_rows, logp=logp, ls_raw=raw, ent_part=part)
+        ops.thin_forward(a.to(dt), w.to(dt), b.to(dt), 2 * A, False, HEAD_SAC, out[:, 2:], A + 5,
+                         eps=eps.to(dt), entropy_rows=ent_rows, logp=logp, ls_raw=raw,
+                         ent_part=part)
         outs.append((out, logp, raw, part))
-    (o1, l1, r1, p1), (o2, l2, r2, p2) = outs
-    _close(o1, o2, 0, 2e-6, 'pi')
-    _close(r1, r2, 1e-5, 1e-5, 'log_std_raw')
-    _close(l1, l2, 2e-5, 2e-4, 'logp')
-    _close(p1.sum(), p2.sum(), 1e-5, 1e-2, 'entropy partials')
+    for k, what in enumerate(('pi', 'logp', 'log_std_raw', 'entropy partials')):
+        _no_worse(outs[0][k], outs[1][k], outs[2][k], what)
+    o1 = outs[0][0]
     assert float(o1[:, :2].abs().max()) == 0 and float(o1[:, 2 + A:].abs().max()) == 0
     # plain / tanh heads, dense and block-diagonal
-    for n_out, bd, head in ((2 * A, False, HEAD_PLAIN), (A, False, HEAD_TANH), (1, False, HEAD_PLAIN)):
+    for n_out, head in ((2 * A, HEAD_PLAIN), (A, HEAD_TANH), (1, HEAD_PLAIN)):
         res = []
-        for ops in (hip, ref):
-            out = torch.zeros(M, n_out + 1, **z)
-            ops.thin_forward(a, w[:n_out].contiguous(), b[:n_out].contiguous(), n_out, bd, head,
-                             out, n_out + 1)
+        for ops, dt in ((hip, torch.float32), (ref, torch.float32), (ref, torch.float64)):
+            out = torch.zeros(M, n_out + 1, device=DEV, dtype=dt)
+            ops.thin_forward(a.to(dt), w[:n_out].contiguous().to(dt),
+                             b[:n_out].contiguous().to(dt), n_out, False, head, out, n_out + 1)
             res.append(out)
-        _close(res[0], res[1], 1e-5, 2e-5, (n_out, bd, head))
+        _no_worse(*res, (n_out, head))
     a2 = torch.randn(M, 2 * H, generator=g).to(DEV)
     res = []
-    for ops in (hip, ref):
-        out = torch.zeros(M, 2, **z)
-        ops.thin_forward(a2, w[:2].contiguous(), b[:2].contiguous(), 2, True, HEAD_PLAIN, out, 2)
+    for ops, dt in ((hip, torch.float32), (ref, torch.float32), (ref, torch.float64)):
+        out = torch.zeros(M, 2, device=DEV, dtype=dt)
+        ops.thin_forward(a2.to(dt), w[:2].contiguous().to(dt), b[:2].contiguous().to(dt), 2, True,
+                         HEAD_PLAIN, out, 2)
         res.append(out)
-    _close(res[0], res[1], 1e-5, 2e-5, 'block diagonal')
+    _no_worse(*res, 'block diagonal')
+
+
+def _three(fn):
+    """fn(ops, dtype) -> tuple of tensors, for the HIP kernels in float32, the
+    restatement in float32 and the restatement in float64."""
+    from tracktolearn_amd.algorithms.shared.fused import HipOps
+    return [fn(ops, dt) for ops, dt in ((HipOps(DEV), torch.float32), (TorchOps(), torch.float32),
+                                        (TorchOps(), torch.float64))]
+
+
+def _check_three(res, names):
+    for k, what in enumerate(names):
+        _no_worse(res[0][k], res[1][k], res[2][k], what)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,H', [(8192, 1024), (4096, 1024), (1000, 68), (37, 45), (9, 2050)])
 def test_backward_kernels(M, H):
-    from tracktolearn_amd.algorithms.shared.fused import HipOps, _rows_per_block
-    hip, ref = HipOps(DEV), TorchOps()
+    from tracktolearn_amd.algorithms.shared.fused import _rows_per_block
     g = torch.Generator().manual_seed(M * 7 + H)
-    z = dict(device=DEV)
     R = -(-M // _rows_per_block(M))
     r0, r1 = M // 3, M - 2
     # dense thin layer (actor head: 6 outputs)
     a = torch.relu(torch.randn(M, H, generator=g)).to(DEV)
     d_out = torch.randn(M, 6, generator=g).to(DEV)
     w = torch.randn(6, H, generator=g).to(DEV)
-    res = []
-    for ops in (hip, ref):
-        dz, part = torch.zeros(M, H, **z), torch.full((R, H + 6 * H + 6), 7.0, **z)
-        ops.thin_backward(d_out, a, w, 6, False, r0, r1, dz, part)
-        res.append((dz, part))
-    _close(res[0][0], res[1][0], 1e-5, 1e-5, 'thin dense dz')
-    _close(res[0][1], res[1][1], 1e-4, 1e-4, 'thin dense slab')
-    _close(res[0][1].sum(0), res[1][1].sum(0), 1e-4, 2e-3, 'thin dense sums')
+
+    def dense(ops, dt):
+        dz = torch.zeros(M, H, device=DEV, dtype=dt)
+        part = torch.full((R, H + 6 * H + 6), 7.0, device=DEV, dtype=dt)
+        ops.thin_backward(d_out.to(dt), a.to(dt), w.to(dt), 6, False, r0, r1, dz, part)
+        return dz, part, part.sum(0)
+    _check_three(_three(dense), ('thin dense dz', 'thin dense slab', 'thin dense sums'))
     # block diagonal (the two critics side by side, ld > 2H)
-    a2 = torch.relu(torch.randn(M, 2 * H + 4, generator=g)).to(DEV)[:, :2 * H]
+    a2 = torch.relu(torch.randn(M, 2 * H + 4, generator=g)).to(DEV)
     dq = torch.randn(M, 2, generator=g).to(DEV)
     w2 = torch.randn(2, H, generator=g).to(DEV)
-    res = []
-    for ops in (hip, ref):
-        dz, part = torch.zeros(M, 2 * H, **z), torch.full((R, 4 * H + 2), 7.0, **z)
-        ops.thin_backward(dq, a2, w2, 2, True, r0, r1, dz, part)
-        res.append((dz, part))
-    _close(res[0][0], res[1][0], 1e-5, 1e-5, 'thin bd dz')
-    _close(res[0][1], res[1][1], 1e-4, 1e-4, 'thin bd slab')
+
+    def blockdiag(ops, dt):
+        dz = torch.zeros(M, 2 * H, device=DEV, dtype=dt)
+        part = torch.full((R, 4 * H + 2), 7.0, device=DEV, dtype=dt)
+        ops.thin_backward(dq.to(dt), a2.to(dt)[:, :2 * H], w2.to(dt), 2, True, r0, r1, dz, part)
+        return dz, part
+    _check_three(_three(blockdiag), ('thin bd dz', 'thin bd slab'))
     # ReLU backward + bias partials
-    res = []
     d0 = torch.randn(M, 2 * H, generator=g).to(DEV)
-    for ops in (hip, ref):
-        dz, part = d0.clone(), torch.full((R, 2 * H), 7.0, **z)
-        ops.relu_backward_bias(dz, a2, r0, r1, part)
-        res.append((dz, part))
+
+    def relu(ops, dt):
+        dz = d0.to(dt).clone()
+        part = torch.full((R, 2 * H), 7.0, device=DEV, dtype=dt)
+        ops.relu_backward_bias(dz, a2.to(dt)[:, :2 * H], r0, r1, part)
+        return dz, part
+    res = _three(relu)
     assert torch.equal(res[0][0], res[1][0])
-    _close(res[0][1], res[1][1], 1e-4, 1e-4, 'relu slab')
+    _check_three(res, ('relu dz', 'relu slab'))
     # finalize: wide, narrow and scaled segments in one launch
     part = res[0][1]
     narrow = torch.randn(300, 8, generator=g).to(DEV)
-    res = []
-    for ops in (hip, ref):
-        o1, o2, o3 = torch.zeros(2 * H, **z), torch.zeros(8, **z), torch.zeros(1, **z)
-        ops.colsum_finalize([(part, 0, 2 * H, o1, 1.0), (narrow, 0, 8, o2, 0.25),
-                             (narrow[:77], 3, 1, o3, 1.0 / 77)])
-        res.append((o1, o2, o3))
-    for x, y in zip(*res):
-        _close(x, y, 1e-5, 1e-4, 'finalize')
+
+    def finalize(ops, dt):
+        o1, o2, o3 = (torch.zeros(k, device=DEV, dtype=dt) for k in (2 * H, 8, 1))
+        ops.colsum_finalize([(part.to(dt), 0, 2 * H, o1, 1.0), (narrow.to(dt), 0, 8, o2, 0.25),
+                             (narrow.to(dt)[:77], 3, 1, o3, 1.0 / 77)])
+        return o1, o2, o3
+    _check_three(_three(finalize), ('finalize wide', 'finalize narrow', 'finalize scalar'))
     # actor-loss gradient through the critics' first layer + head backward
     dh = torch.randn(M, 2 * H, generator=g).to(DEV)
     wa = torch.randn(3, 2 * H, generator=g).to(DEV)
@@ -272,12 +293,13 @@ def test_backward_kernels(M, H):
     raw = (torch.randn(M, 3, generator=g) * 8).to(DEV)
     la = torch.tensor([-1.3], device=DEV)
     for log_alpha, const in ((la, 0.0), (None, 0.2)):
-        res = []
-        for ops in (hip, ref):
-            d_head = torch.zeros(M, 6, **z)
-            ops.actor_head_backward(dh, a2, wa, 3, pi[:, 4:], 9, eps, raw, log_alpha, const, d_head)
-            res.append(d_head)
-        _close(res[0], res[1], 2e-5, 2e-5 * float(res[1].abs().max()), 'head backward')
+        def head(ops, dt):
+            d_head = torch.zeros(M, 6, device=DEV, dtype=dt)
+            ops.actor_head_backward(dh.to(dt), a2.to(dt)[:, :2 * H], wa.to(dt), 3,
+                                    pi.to(dt)[:, 4:], 9, eps.to(dt), raw.to(dt),
+                                    None if log_alpha is None else log_alpha.to(dt), const, d_head)
+            return (d_head,)
+        _check_three(_three(head), ('head backward',))
 
 
 @pytest.mark.gpu

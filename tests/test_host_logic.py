@@ -236,6 +236,56 @@ def test_lazy_state_rows_behave_like_the_gathered_tensor():
     assert torch.equal(got, want) and torch.equal(lazy2 * 1, want)
 
 
+def test_lazy_state_rows_are_safe_for_a_caller_who_changes_nothing():
+    """The object `step()` returns, used exactly as the reference's callers use
+    a state tensor (ddpg.py:187-224 feeding replay.py:38-89) and through every
+    accessor that bypasses the torch dispatcher: nothing raises, nothing reads a
+    null pointer, no-op conversions give a plain tensor."""
+    import copy
+    import pickle
+    import torch
+    from tracktolearn_amd.environments.tracking_env import _LazyStateRows
+    rows = torch.arange(28, dtype=torch.float32).view(7, 4)
+    row_dest = torch.tensor([3, 0, 4, 1, 6, 5, 2], dtype=torch.int32)
+    want = rows[row_dest.long()]
+
+    def lazy():
+        return _LazyStateRows(rows, row_dest)
+    # --- the reference's consumer lines -------------------------------------
+    max_size, ptr = 16, 12                               # the ring wraps
+    ring = torch.zeros((max_size, 4), dtype=torch.float32)        # replay.py:38-47
+    next_state = lazy()
+    ind = (np.arange(0, len(next_state)) + ptr) % max_size         # replay.py:80
+    ring[ind] = next_state.to('cpu', copy=True)                    # ddpg.py:205, replay.py:84
+    assert np.array_equal(ring[ind].numpy(), want.numpy())
+    assert np.array_equal(lazy().cpu().numpy(), want.numpy())      # `state.cpu().numpy()`
+    assert np.array_equal(lazy().to(device='cpu', copy=True).numpy(), want.numpy())
+    # --- accessors below the dispatcher -------------------------------------
+    assert np.array_equal(lazy().numpy(), want.numpy())
+    assert np.array_equal(np.asarray(lazy()), want.numpy())
+    assert np.array_equal(np.array(lazy(), dtype=np.float64), want.double().numpy())
+    assert lazy().tolist() == want.tolist()
+    x = lazy()
+    assert x.data_ptr() != 0 and x.data_ptr() == x.materialize().data_ptr()
+    assert x.untyped_storage().nbytes() == want.untyped_storage().nbytes()
+    assert x.storage_offset() == 0 and x.stride() == want.stride() and x.is_contiguous()
+    assert torch.equal(torch.from_dlpack(lazy()), want)
+    assert torch.equal(lazy().data, want)
+    assert torch.equal(copy.deepcopy(lazy()), want)
+    assert torch.equal(pickle.loads(pickle.dumps(lazy())), want)
+    assert float(lazy()[2, 1].item()) == float(want[2, 1])
+    # --- conversions a real tensor answers with `self` ----------------------
+    for conv in (lambda t: t.float(), lambda t: t.contiguous(), lambda t: t.to('cpu'),
+                 lambda t: t.to(torch.float32), lambda t: t.detach(), lambda t: t.cpu(),
+                 lambda t: t.type(torch.float32), lambda t: t.clone()):
+        got = conv(lazy())
+        assert type(got) is torch.Tensor and torch.equal(got, want)
+        assert np.array_equal(got.numpy(), want.numpy())
+    # views and slices of it are plain tensors too
+    assert type(lazy()[1:3]) is torch.Tensor and type(lazy().view(-1)) is torch.Tensor
+    assert np.array_equal(lazy().T.contiguous().numpy(), want.T.numpy())
+
+
 def test_policy_tiles_make_actions_independent_of_the_batch_shape(monkeypatch):
     """TTL_POLICY_TILE_ROWS: the networks run in tiles of a fixed row count, so a
     row's action does not depend on which other rows share its batch (what lets

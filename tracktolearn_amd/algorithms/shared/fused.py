@@ -326,7 +326,20 @@ class FusedSACUpdate:
             if alg.log_alpha.grad is None:
                 alg.log_alpha.grad = torch.zeros_like(alg.log_alpha)
 
+    @staticmethod
+    def _export_own_steps(optimizer, state_dict):
+        """``optimizer.state_dict()``: every parameter gets a ``step`` tensor of
+        its own (here they all are one view of the device counter; a torch
+        optimizer that loads the dict increments them one by one)."""
+        state_dict['state'] = {
+            k: dict(v, step=v['step'].clone()) if torch.is_tensor(v.get('step')) else v
+            for k, v in state_dict['state'].items()}
+        return state_dict
+
     def _bind_state(self, opt, p, k_opt, m_view, v_view):
+        if not getattr(opt, '_ttl_step_hook', False):
+            opt.register_state_dict_post_hook(self._export_own_steps)
+            opt._ttl_step_hook = True
         st = opt.state[p]
         if 'exp_avg' in st and st['exp_avg'].data_ptr() != m_view.data_ptr():
             # state made by torch's own step() or load_state_dict(): import it

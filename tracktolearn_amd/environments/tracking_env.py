@@ -66,7 +66,13 @@ class _LazyStateRows(torch.Tensor):
     (ddpg.py: the replay buffer's ``next_state``).  This tensor serves both: it
     has the shape, dtype and device of the real thing and becomes
     ``rows[row_dest]`` (one gather, what ``harvest()`` used to pay as a copy)
-    the first time any torch operation touches it."""
+    the first time anything touches its values: torch operations (through
+    ``__torch_dispatch__``) and the accessors that bypass the dispatcher --
+    ``numpy()``, ``tolist()``, ``__array__``, ``data_ptr()``, storages, dlpack,
+    ``__cuda_array_interface__`` -- alike; conversions that would be no-ops on
+    a real tensor (``float()``, ``contiguous()``, ``to(same device)``,
+    ``detach()``) return the gathered PLAIN tensor.  ``materialize()`` is the
+    explicit form."""
 
     @staticmethod
     def __new__(cls, rows, row_dest):
@@ -77,6 +83,7 @@ class _LazyStateRows(torch.Tensor):
         return t
 
     def materialize(self):
+        """The gathered rows as a plain ``torch.Tensor`` (cached)."""
         if self._value is None:
             self._value = self._rows.index_select(0, self._row_dest.long())
             self._rows = self._row_dest = None
@@ -92,6 +99,34 @@ class _LazyStateRows(torch.Tensor):
         def real(x):
             return x.materialize() if isinstance(x, _LazyStateRows) else x
         return func(*tree_map(real, args), **tree_map(real, kwargs or {}))
+
+    @property
+    def data(self):
+        return self.materialize().data
+
+    @property
+    def __cuda_array_interface__(self):
+        return self.materialize().__cuda_array_interface__
+
+
+def _forward_to_gathered(name):
+    def method(self, *args, **kwargs):
+        return getattr(self.materialize(), name)(*args, **kwargs)
+    method.__name__ = name
+    method.__doc__ = f'``torch.Tensor.{name}`` of the gathered rows.'
+    return method
+
+
+# accessors implemented below the dispatcher (a wrapper subclass has no storage
+# of its own: data_ptr() would be 0, numpy() / storage access would raise) and
+# conversions that short-circuit to ``self`` before dispatching
+for _name in ('numpy', 'tolist', '__array__', 'data_ptr', 'untyped_storage', 'storage',
+              '_typed_storage', '__dlpack__', '__dlpack_device__', 'contiguous', 'float',
+              'double', 'half', 'bfloat16', 'to', 'type', 'cuda', 'cpu', 'detach', 'clone',
+              'pin_memory', 'record_stream', 'share_memory_', 'is_pinned', 'item',
+              'storage_offset', 'is_shared', '__reduce_ex__', '__deepcopy__'):
+    setattr(_LazyStateRows, _name, _forward_to_gathered(_name))
+del _name
 
 
 class _FreeRun:
