@@ -63,9 +63,19 @@ the rocprofv3 passes under profiles/ look at one workload at a time):
   learner  (N = 1 only) BASELINE configs[2]: one SAC training step at
            n_actor = 65536, hidden 1024-1024, batch 4096, float32 (policy
            forward -> env step with the alignment reward -> replay add ->
-           sample -> SACAuto.update -> harvest), and the update alone.  The
-           GEMMs are PyTorch-ROCm's (hipBLASLt fp32 MFMA), the env step is
-           this library's.  -> `config3_training`.
+           sample -> SACAuto.update -> harvest), phase by phase (HIP events),
+           and the update alone with its FLOP roofline.  The GEMMs are
+           PyTorch-ROCm's (hipBLASLt fp32 MFMA); everything else of the update
+           and the env step are this library's kernels.  -> `config3_training`.
+  config5  BASELINE configs[4]: the same training step with oracle_bonus 10 and
+           the oracle stopping criterion on (TractOracle-Net transformer,
+           random-init weights), 131072 streamlines in total sharded over the N
+           ranks (16384 per GPU at N = 8), learner replicas data-parallel (one
+           all-reduce per parameter arena and update over RCCL).  At N = 1 the
+           N = 8 shard (16384) and the whole batch (131072) are both timed.
+           Phase by phase: policy, env step (of which k_resample and the
+           transformer), replay add / sample, update (of which the gradient
+           all-reduce), harvest.  -> `config5`.
   hbm      the `roofline` object again in the regime where HBM binds: one
            GPU's shard of config 4 at N = 8 (131072 streamlines on the 145^3
            volume).  -> `roofline_hbm_regime` (rank 0's kernel times).
@@ -123,7 +133,7 @@ N_DIRS = WORKLOADS['c2']['n_dirs']
 MAX_LENGTH = WORKLOADS['c2']['max_length']
 #: rows of the HBM-regime roofline leg: one GPU's shard of config 4 at N = 8
 HBM_LEG_ROWS = 131072
-LEGS = ('weak', 'strong', 'config4', 'hbm', 'pipelined', 'shapes', 'learner')
+LEGS = ('weak', 'strong', 'config4', 'hbm', 'pipelined', 'shapes', 'learner', 'config5')
 
 
 def algorithmic_bytes(c, k):
@@ -293,18 +303,36 @@ def cpu_baseline(mask_data, sh, n_sample=65536, n_steps=12):
                      f'{n_steps} steps, step()+harvest() timed, median of 3 '
                      f'repetitions, 1 thread of {os.cpu_count()} host cpus, '
                      f'{spent:.1f} s'}
-    # all usable cores: at most 16 workers (a 1-GPU box's CPU share)
+    # every core this process may use (capped by memory: ~0.3 GB per worker
+    # beside the shared volume); the sample grows with the workers so that
+    # each one has work for about as long as the single-thread run
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:     # pragma: no cover
         usable = os.cpu_count() or 1
-    workers = max(1, min(16, usable))
+    try:
+        avail_gb = os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') / 2 ** 30
+    except (ValueError, OSError):      # pragma: no cover
+        avail_gb = 16.0
+    workers = max(1, min(usable, int(avail_gb / 0.5)))
+    cpu_model = ''
+    try:
+        for row in open('/proc/cpuinfo'):
+            if row.startswith('model name'):
+                cpu_model = row.split(':', 1)[1].strip()
+                break
+    except OSError:            # pragma: no cover
+        pass
+    one['cpu_model'] = cpu_model
+    one['usable_cpus'] = usable
     multi = None
     try:
+        n_multi = int(min(N_ACTOR, max(n_sample, 1024 * workers)))
+        seeds = synthetic_seeds(mask_data, n_multi, seed=100)
         _FORK_SHARED.update(sh=sh, mask=mask_data, seeds=seeds)
-        per = -(-n_sample // workers)
-        jobs = [(w * per, min((w + 1) * per, n_sample), n_steps)
-                for w in range(workers) if w * per < n_sample]
+        per = -(-n_multi // workers)
+        jobs = [(w * per, min((w + 1) * per, n_multi), n_steps)
+                for w in range(workers) if w * per < n_multi]
         t0 = time.perf_counter()
         with mp.get_context('fork').Pool(len(jobs)) as pool:
             parts = pool.map(_oracle_worker, jobs)
@@ -313,11 +341,13 @@ def cpu_baseline(mask_data, sh, n_sample=65536, n_steps=12):
         busy = max(p[1] for p in parts)
         multi = {'value': units / busy, 'unit': 'streamline-steps/s',
                  'cores': len(jobs), 'kind': 'port',
-                 'sample': f'the same sample sharded over {len(jobs)} forked worker '
-                           f'processes (one single-threaded oracle each, '
-                           f'{usable} usable of {os.cpu_count()} host cpus); units / '
-                           f'slowest worker\'s step()+harvest() time; {wall:.1f} s '
-                           f'wall incl. process start and per-worker setup'}
+                 'cpu_model': cpu_model,
+                 'sample': f'{n_multi} of the {N_ACTOR} streamlines, first {n_steps} steps, '
+                           f'sharded over {len(jobs)} forked worker processes (one '
+                           f'single-threaded oracle each; {usable} usable of '
+                           f'{os.cpu_count()} host cpus); units / slowest worker\'s '
+                           f'step()+harvest() time; {wall:.1f} s wall incl. process start '
+                           f'and per-worker setup'}
     except Exception as exc:   # never lose the bench line to the baseline
         multi = {'error': repr(exc)}
     finally:
@@ -793,16 +823,45 @@ def main(argv=None):
     if 'learner' in legs and world == 1:
         # an auxiliary one-GPU leg: never lose the headline line to it
         try:
-            from benchmarks.bench_learner import measure as learner_measure
-            out['learner'] = learner_measure(device=device)
+            from benchmarks.bench_training import measure as training_measure
+            out['learner'] = training_measure('c3', device=device)
             torch.cuda.empty_cache()
             # the same with SACAuto.update replayed from a HIP graph (enable_graph())
-            graphed = learner_measure(device=device, graph=True)
+            graphed = training_measure('c3', device=device, graph=True)
             out['learner']['graphed_update'] = {k: graphed[k] for k in
                                                 ('update_ms', 'train_step_ms',
                                                  'train_streamline_steps_per_s')}
         except Exception as exc:
             out['learner'] = dict(out.get('learner') or {}, error=repr(exc))
+        torch.cuda.empty_cache()
+
+    # ======================= config 5: training with the oracle, data parallel
+    if 'config5' in legs:
+        try:
+            from benchmarks.bench_training import measure as training_measure
+            c5_total = int(os.environ.get('TTL_BENCH_C5_TOTAL', 131072))
+            shard = c5_total // 8 if world == 1 else -(-c5_total // world)
+            grp.barrier()
+            c5 = training_measure('c5', n_actor=shard, device=device,
+                                  data_parallel=world > 1, seed_offset=rank)
+            grp.barrier()
+            # whole job: the slowest rank's step, every rank's streamline-steps
+            ms = float(grp.reduce([c5['train_step_ms']], 'max')[0])
+            rows = float(grp.reduce([c5['train_rows_per_step']], 'sum')[0])
+            c5['train_step_ms_max_over_ranks'] = ms
+            c5['value'] = rows / (ms * 1e-3)
+            c5['n_actor_total'] = shard * world
+            if world == 1:
+                torch.cuda.empty_cache()
+                whole = training_measure('c5', n_actor=c5_total, device=device)
+                c5['whole_batch_on_one_gpu'] = {
+                    k: whole[k] for k in ('n_actor', 'update_ms', 'train_step_ms',
+                                          'train_rows_per_step', 'train_streamline_steps_per_s',
+                                          'phases_ms_per_step', 'oracle_rows_scored_per_step',
+                                          'oracle_batches_per_step') if k in whole}
+            out['config5'] = c5
+        except Exception as exc:
+            out['config5'] = {'error': repr(exc)}
         torch.cuda.empty_cache()
 
     # ======================= 145^3 volume: config 4 + HBM regime ===========
@@ -944,11 +1003,26 @@ def main(argv=None):
                 what='BASELINE configs[2]: SAC (automatic entropy), hidden 1024-1024, '
                      'n_actor=65536, batch 4096, 96^3x45 volume, n_dirs=4, alignment reward; '
                      'train_step_ms = policy forward + env step + replay add + sample + '
-                     'update + harvest, 24 steps after 3 warm-up steps; update_ms = '
-                     'SACAuto.update alone; graphed_update = the same with the update '
-                     'replayed from a HIP graph; fp32')
+                     'update + harvest, 24 steps after warm-up (freshly initialised policy); '
+                     'update_ms = SACAuto.update alone (fused schedule: 12 fp32 GEMMs + the '
+                     'learner kernels of libttl_hip.so); roofline = its FLOP / update_ms / '
+                     'fp32 MFMA peak; graphed_update = the same replayed from a HIP graph; '
+                     'phases_ms_per_step = HIP-event brackets; fp32')
         elif 'learner' in legs and world > 1:
             line['config3_training'] = 'N=1 only'
+        if 'config5' in out:
+            line['config5'] = dict(
+                out['config5'],
+                what='BASELINE configs[4] on synthetic data: SAC training with oracle_bonus 10 '
+                     'and the oracle stopping criterion (TransformerOracle, random-init '
+                     'weights, fp16 autocast as the reference), 131072 streamlines in total '
+                     f'sharded over {world} GPU(s)' + (' -- at N = 1 the N = 8 shard (16384) '
+                     'is the headline of this object and the whole batch is timed beside it'
+                     if world == 1 else ', learner replicas data-parallel over RCCL') +
+                     '; min_length 10 mm so that both oracle paths are live inside the '
+                     'synthetic ball mask; policy initialised to keep going straight '
+                     '(benchmarks/bench_training.py); value = streamline-steps of all ranks '
+                     '/ slowest rank\'s step time, one whole episode (112 steps)')
         if 'shapes' in out:
             line['other_shapes'] = out['shapes']
         elif 'shapes' in legs and world > 1:
@@ -992,6 +1066,36 @@ def main(argv=None):
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu if world == 1 else \
                 'N=1 only (the oracle is timed on rank 0 of a 1-GPU run)'
+        # short scalars of the other configurations, so that a parsed record
+        # shows them without opening the nested objects
+        def _get(d, *keys):
+            for k in keys:
+                if not isinstance(d, dict) or k not in d:
+                    return None
+                d = d[k]
+            return d
+        scalars = {
+            'config3_train_step_ms': _get(line, 'config3_training', 'train_step_ms'),
+            'config3_update_ms': _get(line, 'config3_training', 'update_ms'),
+            'config3_update_frac_fp32_mfma': _get(line, 'config3_training', 'roofline', 'frac'),
+            'config3_value': _get(line, 'config3_training', 'train_streamline_steps_per_s'),
+            'config5_train_step_ms': _get(line, 'config5', 'train_step_ms_max_over_ranks'),
+            'config5_update_ms': _get(line, 'config5', 'update_ms'),
+            'config5_value': _get(line, 'config5', 'value'),
+            'config4_step_only_value': _get(line, 'config4', 'step_only', 'value'),
+            'config4_end_to_end_value': _get(line, 'config4', 'end_to_end', 'value_end_to_end'),
+            'roofline_hbm_regime_frac': _get(line, 'roofline_hbm_regime', 'frac'),
+            'strong_value': _get(line, 'strong', 'value'),
+            'whole_episode_value_rank0': _get(line, 'whole_episode',
+                                              'streamline_steps_per_s_rank0'),
+            'c2_K100_value': _get(line, 'other_shapes', 'c2_K100', 'value'),
+            'c3_env_value': _get(line, 'other_shapes', 'c3_env', 'value'),
+            'c1_shape_ms_per_step': _get(line, 'other_shapes', 'c1_shape', 'ms_per_step'),
+            'c2_host_contract_value': _get(line, 'other_shapes', 'c2_host_contract', 'value'),
+        }
+        line['summary'] = {k: v for k, v in scalars.items() if v is not None}
+        for k, v in line['summary'].items():
+            line[k] = v
         if head is None:
             line['error'] = 'no leg ran'
         print(json.dumps(line), flush=True)

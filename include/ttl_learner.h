@@ -160,10 +160,12 @@ TTL_API int ttl_sac_actor_head_backward(const float *dh, int64_t ld_dh, const fl
  *   p += -step_size * (m / (sqrt(v) / bc2_sqrt + eps))
  *   target = target (1 - tau) + p tau
  * step_size, bc2_sqrt = consts[0], consts[1] (device; written by
- * ttl_sac_losses). */
+ * ttl_sac_losses).  beta1, beta2, eps, tau are torch's Python scalars: 1 - beta1,
+ * 1 - beta2 and 1 - tau are formed in float64 and rounded to f32 once, as torch
+ * does. */
 TTL_API int ttl_adam_polyak(float *p, float *g, float *m, float *v, float *target, int64_t n,
-                            const float *consts, float beta1, float beta2, float eps,
-                            float tau, void *hip_stream);
+                            const float *consts, double beta1, double beta2, double eps,
+                            double tau, void *hip_stream);
 
 /* The temperature step of SACAuto (sac_auto.py:172-174, 219-221): with
  * mean_logp = mean log pi(a|s) over the batch,
@@ -175,7 +177,7 @@ TTL_API int ttl_adam_polyak(float *p, float *g, float *m, float *v, float *targe
  * stepped and adds its own d/d log_alpha to the same buffer (sac_auto.py:223). */
 TTL_API int ttl_sac_alpha_step(float *log_alpha, float *grad, float *m, float *v,
                                const float *mean_logp, float target_entropy,
-                               const float *consts, float beta1, float beta2, float eps,
+                               const float *consts, double beta1, double beta2, double eps,
                                void *hip_stream);
 
 /* The network input rows of one update from a sampled batch, one buffer

@@ -400,7 +400,7 @@ def _sync(dst, src, dtype, device):
 @pytest.mark.parametrize('cls_name,hidden,W,B', [('SACAuto', '1024-1024', 327, 4096),
                                                  ('SACAuto', '256-192-128', 615, 1000),
                                                  ('SAC', '128', 45, 333)])
-def test_fused_update_on_the_gpu_matches_autograd(cls_name, hidden, W, B, monkeypatch):
+def test_fused_update_on_the_gpu_matches_autograd(cls_name, hidden, W, B):
     """cuda:0: FusedSACUpdate (HIP kernels + GEMMs) against the autograd
     update on the same device and against a float64 CPU run, two updates (the
     second with Adam moments in place; before it the two referees are synced to
@@ -412,10 +412,8 @@ def test_fused_update_on_the_gpu_matches_autograd(cls_name, hidden, W, B, monkey
     from tracktolearn_amd.algorithms.sac_auto import SACAuto
     cls = {'SAC': SAC, 'SACAuto': SACAuto}[cls_name]
     ref64, _ = _pair(cls, hidden, W, B, torch.float64)
-    monkeypatch.setenv('TTL_FUSED_LEARNER', '0')
-    plain, _ = _pair(cls, hidden, W, B, torch.float32, device=DEV)
-    monkeypatch.setenv('TTL_FUSED_LEARNER', '1')
-    fused, _ = _pair(cls, hidden, W, B, torch.float32, device=DEV)
+    plain, fused = _pair(cls, hidden, W, B, torch.float32, device=DEV)
+    plain.use_fused_learner = False
     for alg in (plain, fused):
         _sync(alg, ref64, torch.float32, DEV)
     lr = 3e-4
@@ -447,15 +445,11 @@ def test_fused_update_on_the_gpu_matches_autograd(cls_name, hidden, W, B, monkey
 
 
 @pytest.mark.gpu
-def test_fused_sac_losses_dict_matches_autograd(monkeypatch):
+def test_fused_sac_losses_dict_matches_autograd():
     from tracktolearn_amd.algorithms.sac import SAC
     W, B = 64, 512
-    monkeypatch.setenv('TTL_FUSED_LEARNER', '0')
-    plain, _ = _pair(SAC, '64-64', W, B, torch.float32, device=DEV)
-    monkeypatch.setenv('TTL_FUSED_LEARNER', '1')
-    fused, _ = _pair(SAC, '64-64', W, B, torch.float32, device=DEV)
-    fused.agent.load_state_dict(plain.agent.state_dict())
-    fused.target.load_state_dict(plain.target.state_dict())
+    plain, fused = _pair(SAC, '64-64', W, B, torch.float32, device=DEV)
+    plain.use_fused_learner = False
     (batch, eps), = _batches(1, B, W, torch.float32, device=DEV)
     _inject(plain, eps)
     _inject(fused, eps)

@@ -449,10 +449,48 @@ def test_bench_learner_leg():
                           '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    t = _last_json_line(out.stdout)['config3_training']
+    line = _last_json_line(out.stdout)
+    t = line['config3_training']
     assert t['n_actor'] == 65536 and t['hidden'] == '1024-1024' and t['batch'] == 4096
     assert 0 < t['update_ms'] < t['train_step_ms']
     assert t['train_streamline_steps_per_s'] > 0
+    assert t['fused_learner'] is True
+    # the update's FLOP roofline and the per-phase brackets
+    roof = t['roofline']
+    assert roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and roof['peak'] == 157.3
+    assert abs(roof['flop_per_update_issued'] - 1.68e11) < 2e9
+    assert 0.2 < roof['frac'] < 1.0
+    assert abs(roof['achieved'] - roof['flop_per_update_issued'] / t['update_ms'] / 1e9) < 1e-6
+    ph = t['phases_ms_per_step']
+    assert set(ph) >= {'policy', 'env_step', 'replay_add', 'replay_sample', 'update', 'harvest'}
+    assert 0.5 * t['train_step_ms'] < sum(ph[k] for k in ('policy', 'env_step', 'replay_add',
+                                                          'replay_sample', 'update',
+                                                          'harvest')) < 1.5 * t['train_step_ms']
+    assert line['config3_update_ms'] == t['update_ms']       # short top-level scalars
+
+
+@pytest.mark.gpu
+def test_bench_config5_leg():
+    """`bench.py --legs config5`: BASELINE config 5's training step (oracle
+    bonus + oracle stopping) at one GPU's shard, with both oracle paths live
+    and timed."""
+    env = dict(os.environ, PYTHONPATH=ROOT, TTL_BENCH_C5_TOTAL='32768')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--legs', 'config5',
+                          '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = _last_json_line(out.stdout)
+    c5 = line['config5']
+    assert 'error' not in c5, c5
+    assert c5['n_actor'] == 4096 and c5['policy'] == 'straight' and c5['value'] > 0
+    ph = c5['phases_ms_per_step']
+    assert ph['oracle_resample'] > 0 and ph['oracle_transformer'] > 0
+    assert ph['env_step'] > ph['oracle_transformer']
+    # the stopping criterion scores every active streamline of a step, the
+    # bonus the ones that stopped: more rows scored than one batch per episode
+    assert c5['oracle_rows_scored_per_step'] > 100
+    assert c5['whole_batch_on_one_gpu']['n_actor'] == 32768
+    assert line['config5_value'] == c5['value']
 
 
 @pytest.mark.gpu

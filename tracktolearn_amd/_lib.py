@@ -167,11 +167,11 @@ SYMBOLS = {
                                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     'ttl_adam_polyak': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float,
-                                  C.c_float, C.c_void_p]),
+                                  C.c_int64, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_void_p]),
     'ttl_sac_alpha_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float,
-                                     C.c_float, C.c_void_p]),
+                                     C.c_void_p, C.c_float, C.c_void_p, C.c_double, C.c_double,
+                                     C.c_double, C.c_void_p]),
     'ttl_build_learner_inputs': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,

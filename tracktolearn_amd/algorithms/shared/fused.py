@@ -532,6 +532,35 @@ class FusedSACUpdate:
                     'loss_q2': lo[2], 'Q1': lo[3], 'Q2': lo[4], 'backup': lo[5]}
         return {}
 
+    def flops_per_update(self, B):
+        """FLOP of one update at batch B: ``issued`` = what this schedule runs
+        (GEMMs 2 M N K each + the thin layers), ``autograd`` = what the
+        reference's formulation runs (sac_auto.py:139-250: three separate
+        forwards per network and, in ``actor_loss.backward()``, the critics'
+        weight gradients that ``critic_optimizer.zero_grad()`` then discards)."""
+        S, A = self.S, self.A
+        da = [S] + self.ha
+        dq = [S + A] + self.hq
+        fa = sum(a * b for a, b in zip(da[:-1], da[1:]))            # actor hidden MACs / row
+        fq = sum(a * b for a, b in zip(dq[:-1], dq[1:]))            # one critic
+        ta, tq = self.ha[-1] * 2 * A, self.hq[-1]                   # thin layers
+        mac_dgrad_a = sum(a * b for a, b in zip(da[1:-1], da[2:]))  # no dgrad into the input
+        mac_dgrad_q = sum(a * b for a, b in zip(dq[1:-1], dq[2:]))
+        issued = (2 * B * (fa + ta)                 # actor forward on s and s'
+                  + 2 * B * 2 * (fq + tq)           # online critics on (s,a), (s,pi)
+                  + B * 2 * (fq + tq)               # target critics
+                  + 2 * B * 2 * (mac_dgrad_q + tq)  # critics: data gradients, 2B rows
+                  + B * 2 * (fq + tq)               # critics: weight gradients, B rows
+                  + B * 2 * A * self.hq[0]          # action columns of the critics' layer 0
+                  + B * (mac_dgrad_a + ta)          # actor: data gradients
+                  + B * (fa + ta))                  # actor: weight gradients
+        autograd = (2 * B * (fa + ta) + 3 * B * 2 * (fq + tq)
+                    + B * 2 * (mac_dgrad_q + tq + (S + A) * self.hq[0])     # actor loss -> pi
+                    + B * 2 * (fq + tq)                                      # ... discarded dW
+                    + B * 2 * (mac_dgrad_q + tq) + B * 2 * (fq + tq)         # critic loss
+                    + B * (mac_dgrad_a + ta) + B * (fa + ta))
+        return {'issued': 2.0 * issued, 'autograd': 2.0 * autograd}
+
     def _all_reduce(self):
         import torch.distributed as dist
         group = self.alg._dp_group

@@ -537,22 +537,22 @@ struct AdamArgs {
     float *p, *g, *m, *v, *t;
     int64_t n;
     const float *consts;
-    float b1, b2, eps, tau;
+    // torch's Python scalars, rounded to f32 once: 1 - beta1, beta2, 1 - beta2,
+    // eps, tau, 1 - tau
+    float om_b1, b2, om_b2, eps, tau, om_tau;
 };
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float *t,
-                                         const AdamArgs &A, float step_size, float bc2s,
-                                         float one_m_tau) {
-    m = m + (g - m) * (1.f - A.b1);                     // lerp_(grad, 1 - beta1)
-    v = v * A.b2 + ((1.f - A.b2) * g) * g;              // mul_(beta2).addcmul_(g, g, 1 - beta2)
+                                         const AdamArgs &A, float step_size, float bc2s) {
+    m = m + (g - m) * A.om_b1;                          // lerp_(grad, 1 - beta1)
+    v = v * A.b2 + (A.om_b2 * g) * g;                   // mul_(beta2).addcmul_(g, g, 1 - beta2)
     const float denom = sqrtf(v) / bc2s + A.eps;
     p = p + (-step_size) * (m / denom);                 // addcdiv_(m, denom, -step_size)
-    if (t) *t = *t * one_m_tau + p * A.tau;
+    if (t) *t = *t * A.om_tau + p * A.tau;
 }
 
 __global__ __launch_bounds__(LB) void k_adam_polyak(AdamArgs A) {
     const float step_size = A.consts[0], bc2s = A.consts[1];
-    const float one_m_tau = (float)(1.0 - (double)A.tau);
     const int64_t i4 = ((int64_t)blockIdx.x * LB + threadIdx.x) * 4;
     if (i4 + 3 < A.n) {
         float p[4], g[4], m[4], v[4], t[4];
@@ -560,13 +560,13 @@ __global__ __launch_bounds__(LB) void k_adam_polyak(AdamArgs A) {
         if (A.t) ldv<4>(t, A.t + i4);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            adam_one(p[k], g[k], m[k], v[k], A.t ? &t[k] : nullptr, A, step_size, bc2s, one_m_tau);
+            adam_one(p[k], g[k], m[k], v[k], A.t ? &t[k] : nullptr, A, step_size, bc2s);
         stv<4>(A.p + i4, p); stv<4>(A.m + i4, m); stv<4>(A.v + i4, v);
         if (A.t) stv<4>(A.t + i4, t);
     } else {
         for (int64_t i = i4; i < A.n; ++i) {
             float p = A.p[i], m = A.m[i], v = A.v[i], t = A.t ? A.t[i] : 0.f;
-            adam_one(p, A.g[i], m, v, A.t ? &t : nullptr, A, step_size, bc2s, one_m_tau);
+            adam_one(p, A.g[i], m, v, A.t ? &t : nullptr, A, step_size, bc2s);
             A.p[i] = p; A.m[i] = m; A.v[i] = v;
             if (A.t) A.t[i] = t;
         }
@@ -577,7 +577,7 @@ struct AlphaArgs {
     float *p, *g, *m, *v;
     const float *mean_logp; float target_entropy;
     const float *consts;
-    float b1, b2, eps;
+    float om_b1, b2, om_b2, eps;
 };
 
 __global__ void k_sac_alpha_step(AlphaArgs P) {
@@ -585,9 +585,9 @@ __global__ void k_sac_alpha_step(AlphaArgs P) {
     const float ml = P.mean_logp[0];
     const float g = -(ml + P.target_entropy);
     const float alpha_before = expf(P.p[0]);
-    AdamArgs A{P.p, P.g, P.m, P.v, nullptr, 1, P.consts, P.b1, P.b2, P.eps, 0.f};
+    AdamArgs A{P.p, P.g, P.m, P.v, nullptr, 1, P.consts, P.om_b1, P.b2, P.om_b2, P.eps, 0.f, 1.f};
     float p = P.p[0], m = P.m[0], v = P.v[0];
-    adam_one(p, g, m, v, nullptr, A, P.consts[0], P.consts[1], 1.f);
+    adam_one(p, g, m, v, nullptr, A, P.consts[0], P.consts[1]);
     P.p[0] = p; P.m[0] = m; P.v[0] = v;
     P.g[0] = g + alpha_before * ml;
 }
@@ -802,14 +802,15 @@ int ttl_sac_actor_head_backward(const float *dh, int64_t ld_dh, const float *h, 
 }
 
 int ttl_adam_polyak(float *p, float *g, float *m, float *v, float *target, int64_t n,
-                    const float *consts, float beta1, float beta2, float eps, float tau,
+                    const float *consts, double beta1, double beta2, double eps, double tau,
                     void *hip_stream) {
     if (!p || !g || !m || !v || !consts || n <= 0)
         return fail(TTL_ERR_INVALID, "ttl_adam_polyak: null pointer or empty arena");
     if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) ||
         (target && !aligned16(target)))
         return fail(TTL_ERR_INVALID, "ttl_adam_polyak: arenas must be 16-byte aligned");
-    AdamArgs A{p, g, m, v, target, n, consts, beta1, beta2, eps, tau};
+    AdamArgs A{p, g, m, v, target, n, consts, (float)(1.0 - beta1), (float)beta2,
+               (float)(1.0 - beta2), (float)eps, (float)tau, (float)(1.0 - tau)};
     const int64_t threads = (n + 3) / 4;
     k_adam_polyak<<<dim3((unsigned)((threads + LB - 1) / LB)), dim3(LB), 0, S(hip_stream)>>>(A);
     LAUNCH_CHECK("k_adam_polyak");
@@ -818,10 +819,11 @@ int ttl_adam_polyak(float *p, float *g, float *m, float *v, float *target, int64
 
 int ttl_sac_alpha_step(float *log_alpha, float *grad, float *m, float *v,
                        const float *mean_logp, float target_entropy, const float *consts,
-                       float beta1, float beta2, float eps, void *hip_stream) {
+                       double beta1, double beta2, double eps, void *hip_stream) {
     if (!log_alpha || !grad || !m || !v || !mean_logp || !consts)
         return fail(TTL_ERR_INVALID, "ttl_sac_alpha_step: null pointer");
-    AlphaArgs P{log_alpha, grad, m, v, mean_logp, target_entropy, consts, beta1, beta2, eps};
+    AlphaArgs P{log_alpha, grad, m, v, mean_logp, target_entropy, consts, (float)(1.0 - beta1),
+                (float)beta2, (float)(1.0 - beta2), (float)eps};
     k_sac_alpha_step<<<dim3(1), dim3(64), 0, S(hip_stream)>>>(P);
     LAUNCH_CHECK("k_sac_alpha_step");
     return TTL_OK;
