@@ -140,7 +140,13 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
     oracle = config == 'c5'
     if n_actor is None:
         n_actor = 16384 if oracle else 65536
-XX
+    if policy is None:
+        policy = 'straight' if oracle else 'random'
+    if steps is None:
+        # config 5: one whole episode and a bit (the longest chord of the ball mask
+        # is ~107 steps): the oracle only scores streamlines longer than
+        # min_nb_steps (bonus) / 5 min_nb_steps (stopping criterion)
+        steps = 112 if oracle else 24
     subject = synthetic_subject(96, 45, seed=1234, peaks=True)
     dto = dict(n_dirs=4, theta=30.0, npv=1, binary_stopping_threshold=0.1,
                step_size=0.75, min_length=20.0, max_length=200.0,

@@ -356,7 +356,7 @@ def test_losses_adam_and_input_kernels():
                        0.99, torch.zeros(2, 2, **z), None, steps, consts, 0b1, 3e-4)
         hip.adam_polyak(p, gi, m, v, None, consts, 0.0)
     assert float(steps) == 3.0
-    _close(p, w.data, 0, 1e-7, 'three Adam steps vs torch.optim.Adam')
+    _close(p, w.data, 2e-7, 1e-7, 'three Adam steps vs torch.optim.Adam')     # <= 1 ulp
     # temperature step
     res = []
     for ops in (hip, ref):

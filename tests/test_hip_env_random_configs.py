@@ -1,14 +1,17 @@
 """A slice of the randomised differential run (tests/stress_parity.py) inside
 the GPU suite: random volume shapes, SH orders, K, angles, thresholds, step
 sizes, env classes, affine dtypes, batch sizes, processing orders and a random
-mix of step()/step_device(), each run to exhaustion against the CPU oracle."""
+mix of step()/step_device() / free-running steps and of every scheduling knob
+of rounds 2 and 3 (order refresh period, one-launch tails and their caps, SH
+record order, order keys, early refresh threshold, lazy step state), each run
+to exhaustion against the CPU oracle: 150 configurations, fixed seed."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def test_twelve_random_configurations():
+def test_one_hundred_and_fifty_random_configurations():
     import os
     import stress_parity
     from tracktolearn_amd.environments import TrackingEnvironment
@@ -21,7 +24,7 @@ def test_twelve_random_configurations():
     rng = np.random.RandomState(2024)
     stops = np.zeros(3, np.int64)
     try:
-        for k in range(12):
+        for k in range(150):          # ~0.2 s each (profiles/r03_stress_parity_*.log)
             r = stress_parity.one(rng, k)
             stops += np.array(r['stops'])
             assert r['worst_state_err'] <= 1e-5

@@ -1744,6 +1744,15 @@ int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t order,
         if (host_counts && !host_word) HIP_TRY(ttl_copy_counts(env, host_counts, s));
         n_gather = env->n_slots;
     } else {
+        // the two-kernel tail reads proc[j] for j < n_active without a hole check:
+        // an order that still holds holes (left by k_tail) must never reach it.
+        // The knobs that choose the tail are fixed per handle, so this cannot
+        // happen today; a setter that flips one mid-episode fails here instead
+        // of reading stop[-1]
+        if (proc && env->n_slots > n_active)
+            return fail(TTL_ERR_STATE, "ttl_env_step: the processing order holds %d holes but "
+                                       "the step tail was switched to the two-kernel form; "
+                                       "refresh the order first", env->n_slots - n_active);
         prof_mark(env, 1, 0, s);
         hipLaunchKernelGGL(k_prefix, dim3(nb), dim3(BLOCK), 0, s, env->P, idx, idx_next,
                            proc, n_active, nb, order, n_pts, host_word, seq);

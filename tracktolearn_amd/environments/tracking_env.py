@@ -244,7 +244,8 @@ class TrackingEnvironment(BaseEnv):
         return state
 
     #: batches at least this large get a spatially sorted processing order
-    SPATIAL_ORDER_MIN = int(os.environ.get('TTL_FUSE_MAX_ROWS', '16384'))
+    #: (TTL_FUSE_MAX_ROWS, clamped as ttl_env_create clamps it: [256, 65536])
+    SPATIAL_ORDER_MIN = min(max(int(os.environ.get('TTL_FUSE_MAX_ROWS', '16384')), 256), 65536)
 
     #: the order is rebuilt from the current positions every this many steps
     #: (a streamline crosses an 8-voxel brick in about ten 0.75-voxel steps;
@@ -268,7 +269,7 @@ class TrackingEnvironment(BaseEnv):
         # 256-slot block): refresh early once a fifth of it is holes
         slots = getattr(self, '_order_slots', 0)
         sparse = bool(every) and self.length > 1 and slots and n < self.ORDER_MIN_FILL * slots \
-            and slots <= self.TAIL_FUSED_MAX_ROWS
+            and slots <= self.TAIL_FUSED_MAX_ROWS and self._order_keeps_holes()
         if not force and not sparse and \
                 (not every or self.length <= 1 or (self.length - 1) % every):
             return
@@ -276,13 +277,23 @@ class TrackingEnvironment(BaseEnv):
             self._handle, self._stream()), 'ttl_env_refresh_processing_order')
         self._order_slots = n
 
+    def _order_keeps_holes(self):
+        """Whether the library runs the one-launch tail on this handle (only then
+        does the order keep holes between refreshes): the gather must read the
+        per-slot records, i.e. the register-deduplicating kernel (TTL_STATE_KERNEL
+        not 0 or 2) with a neighbourhood radius inside (0, 1) voxel -- the
+        conditions of ``fused_tail`` in ttl_env_step."""
+        return os.environ.get('TTL_STATE_KERNEL', '') not in ('0', '2') and \
+            bool(self.add_neighborhood_vox) and \
+            0.0 < float(np.float32(self.add_neighborhood_vox)) < 1.0
+
     #: refresh the processing order early when fewer than this share of its slots
     #: still hold a streamline
     ORDER_MIN_FILL = float(os.environ.get('TTL_ORDER_MIN_FILL', '0.8'))
     #: the library's fused tail (and with it the holes) is used for orders of at
     #: most this many slots (mirrors TTL_TAIL_FUSED / TTL_TAIL_FUSED_MAX_ROWS)
     TAIL_FUSED_MAX_ROWS = 0 if os.environ.get('TTL_TAIL_FUSED', '1') == '0' else \
-        int(os.environ.get('TTL_TAIL_FUSED_MAX_ROWS', '262144'))
+        min(int(os.environ.get('TTL_TAIL_FUSED_MAX_ROWS', '262144')), 4096 * 256)
 
     def nreset(self, n_seeds: int):
         """N random seeds among all seeds (tracking_env.py:47-89; global
@@ -569,8 +580,9 @@ class TrackingEnvironment(BaseEnv):
 
     # ------------------------------------------------------------------ #
     # free-running episode: policy + step in one HIP graph, no host in the loop
-    #: largest batch the free-running step takes (the one-launch step tail)
-    FREERUN_MAX = int(os.environ.get('TTL_FUSE_MAX_ROWS', '16384'))
+    #: largest batch the free-running step takes (the one-launch step tail;
+    #: TTL_FUSE_MAX_ROWS clamped as ttl_env_create clamps it)
+    FREERUN_MAX = min(max(int(os.environ.get('TTL_FUSE_MAX_ROWS', '16384')), 256), 65536)
 
     def _has_action_noise(self):
         return False
