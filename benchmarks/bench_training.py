@@ -128,11 +128,15 @@ def straight_policy_(actor, dir_offset, log_std=-3.0, rest=0.05):
 
 
 def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=None, graph=False,
-            device='cuda:0', data_parallel=False, seed_offset=0, policy=None):
+            device='cuda:0', data_parallel=False, seed_offset=0, policy=None, lr=None):
     """Timings of `steps` training steps as a dict (see the module docstring).
     `policy`: 'random' (fresh initialisation; config 3's convention since round
     2) or 'straight' (`straight_policy_`; config 5's default: the oracle needs
-    streamlines that live)."""
+    streamlines that live).  `lr`: 3e-4 (the trainers' default) for 'random';
+    1e-7 for 'straight' -- Adam moves every weight by about lr per update
+    whatever the gradient, and a few hundred updates at 3e-4 on the synthetic
+    reward un-learn the hand-built policy before the episode ends; the work of
+    an update does not depend on lr."""
     from tracktolearn_amd.algorithms.sac_auto import SACAuto
     from tracktolearn_amd.environments import TrackingEnvironment
     from tracktolearn_amd.utils.synthetic import synthetic_seeds, synthetic_subject
@@ -142,6 +146,8 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
         n_actor = 16384 if oracle else 65536
     if policy is None:
         policy = 'straight' if oracle else 'random'
+    if lr is None:
+        lr = 1e-7 if policy == 'straight' else 3e-4
     if steps is None:
         # config 5: one whole episode and a bit (the longest chord of the ball mask
         # is ~107 steps): the oracle only scores streamlines longer than
@@ -169,8 +175,8 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
     env.seeds = synthetic_seeds(subject[1].data, n_actor, seed=1 + seed_offset)
     W = env.get_state_size()
     torch.manual_seed(0)
-    alg = SACAuto(W, 3, hidden, n_actors=n_actor, batch_size=batch, replay_size=int(1e6),
-                  rng=None, device=dev)
+    alg = SACAuto(W, 3, hidden, lr=lr, n_actors=n_actor, batch_size=batch,
+                  replay_size=int(1e6), rng=None, device=dev)
     if policy == 'straight':
         straight_policy_(alg.agent.actor, 7 * 45)
         alg.target.actor.load_state_dict(alg.agent.actor.state_dict())
@@ -181,7 +187,7 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
     out = {'config': 'BASELINE configs[4] (oracle bonus + oracle stopping)' if oracle
            else 'BASELINE configs[2]', 'W': W, 'hidden': hidden, 'n_actor': n_actor,
            'batch': batch, 'graph': bool(graph), 'data_parallel': bool(data_parallel),
-           'policy': policy,
+           'policy': policy, 'lr': lr,
            'fused_learner': os.environ.get('TTL_FUSED_LEARNER', '1') != '0'}
 
     def reset():

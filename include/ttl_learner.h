@@ -40,10 +40,12 @@ extern "C" {
 #define TTL_HEAD_TANH 2         /* tanh(a W^T + b) (offpolicy.py:54-60)     */
 
 /* The last layer of an MLP when it is only a few units wide (actor head: 6,
- * critic heads: 1 each): out[m][o] = sum_j a[m][c(o) + j] w[o][j] + b[o],
- * j < n_in.  block_diagonal = 0: c(o) = 0 (one network, a is [M][n_in]);
- * block_diagonal = 1: c(o) = o * n_in (n_out networks side by side in a, the
- * double critic: q1 | q2).
+ * critic heads: 1 each): out[m][o] = sum_j A_o[m][j] w[o][j] + b[o], j < n_in.
+ * block_diagonal = 0: one network, A_o = a ([M][n_in], row stride lda);
+ * block_diagonal = 1: n_out networks (the double critic: q1, q2), A_o[m][j] =
+ * a[o * a_block_stride + m * lda + j] -- side by side in one row
+ * (a_block_stride = n_in, lda >= n_out * n_in) or in planes of their own
+ * (a_block_stride = plane size, lda >= n_in).
  *
  * head = TTL_HEAD_PLAIN: out[m * ld_out + o].
  * head = TTL_HEAD_TANH : out[m * ld_out + o] = tanh(.)  (Actor.forward).
@@ -57,15 +59,15 @@ extern "C" {
  * (kept for the backward).  entropy_part[block] = sum over the block's rows
  * m < entropy_rows of logp[m] (for the temperature loss, sac_auto.py:172-174),
  * block = TTL_THIN_FWD_ROWS rows; NULL to skip. */
-TTL_API int ttl_thin_forward(const float *a, int64_t lda, const float *w, const float *b,
-                             int32_t n_rows, int32_t n_in, int32_t n_out,
-                             int32_t block_diagonal, int32_t head, const float *eps,
+TTL_API int ttl_thin_forward(const float *a, int64_t lda, int64_t a_block_stride,
+                             const float *w, const float *b, int32_t n_rows, int32_t n_in,
+                             int32_t n_out, int32_t block_diagonal, int32_t head, const float *eps,
                              int32_t entropy_rows, float *out, int64_t ld_out, float *logp,
                              float *log_std_raw, float *entropy_part, void *hip_stream);
 
 /* Rows of one block of ttl_thin_forward (entropy_part has ceil(n_rows / this)
  * entries). */
-#define TTL_THIN_FWD_ROWS 16
+#define TTL_THIN_FWD_ROWS 4
 
 /* Per-row terms of the SAC losses and their gradients w.r.t. the critic
  * outputs (sac_auto.py:177-205 / sac.py:168-200).  q_online: [2 * n][2], rows
@@ -80,19 +82,22 @@ TTL_API int ttl_thin_forward(const float *a, int64_t lda, const float *w, const 
  * (q2-backup)^2, q1, q2, backup, 0, 0} (block = 256 rows), NULL to skip.
  *
  * One thread also advances the Adam step counters: for every optimizer k <
- * n_opt with bit k of `tick_mask` set, steps[k] += 1 and adam_consts[2k],
- * [2k+1] = lr / (1 - beta1^step), sqrt(1 - beta2^step) (float64 arithmetic,
- * stored as f32: torch.optim.Adam's scalars). */
+ * n_opt with bit k of `tick_mask` set, steps[k] += 1, beta_pows[2k] *= beta1,
+ * beta_pows[2k+1] *= beta2 (= beta^step, float64, device memory: 1.0 before the
+ * first step) and adam_consts[2k], [2k+1] = lr / (1 - beta1^step), sqrt(1 -
+ * beta2^step) (float64 arithmetic, stored as f32: torch.optim.Adam's scalars). */
 TTL_API int ttl_sac_losses(const float *q_online, const float *q_target, const float *logp,
                            const float *reward, const float *not_done, int32_t n,
                            const float *log_alpha, float alpha_const, float gamma,
                            float *dq, float *loss_part, float *steps, float *adam_consts,
-                           int32_t n_opt, uint32_t tick_mask, double lr, double beta1,
-                           double beta2, void *hip_stream);
+                           double *beta_pows, int32_t n_opt, uint32_t tick_mask, double lr,
+                           double beta1, double beta2, void *hip_stream);
 
 /* Backward of a thin last layer and of the ReLU in front of it, one pass over
- * the activations: for every row m and input column j (c(o), n_in as above)
- *   dz[m][c + j] = (a[m][c + j] > 0) * sum_o d_out[m][o] w[o][j]
+ * the activations: for every row m and input column j (A_o, n_in as above; dz is
+ * addressed like a, with its own ld_dz / dz_block_stride)
+ *   dZ_o[m][j] = (A_o[m][j] > 0) * sum_o' d_out[m][o'] w[o'][j]   (dense: all o';
+ *                                                     block diagonal: o' = o only)
  * and, summed over the rows r0 <= m < r1 only (the rows whose loss trains THIS
  * layer; the others only pass the gradient through), per block of `rows_per_block`
  * rows into part[block][...]:
@@ -104,22 +109,28 @@ TTL_API int ttl_sac_losses(const float *q_online, const float *q_target, const f
  * ld_part >= n_cols + n_w + n_out.  Blocks without a row in [r0, r1) write
  * zeros.  a and dz may not alias. */
 TTL_API int ttl_thin_backward(const float *d_out, int64_t ld_dout, const float *a, int64_t lda,
-                              const float *w, int32_t n_rows, int32_t n_in, int32_t n_out,
-                              int32_t block_diagonal, int32_t r0, int32_t r1,
-                              int32_t rows_per_block, float *dz, int64_t ld_dz, float *part,
-                              int64_t ld_part, void *hip_stream);
+                              int64_t a_block_stride, const float *w, int32_t n_rows,
+                              int32_t n_in, int32_t n_out, int32_t block_diagonal, int32_t r0,
+                              int32_t r1, int32_t rows_per_block, float *dz, int64_t ld_dz,
+                              int64_t dz_block_stride, float *part, int64_t ld_part,
+                              void *hip_stream);
 
-/* ReLU backward in place + bias gradient: dz[m][j] *= (a[m][j] > 0); part[block][j] =
- * the block's column sums of the result over its rows r0 <= m < r1 (block =
- * rows_per_block rows; zeros for a block without such a row). */
-TTL_API int ttl_relu_backward_bias(float *dz, int64_t ld_dz, const float *a, int64_t lda,
-                                   int32_t n_rows, int32_t n_cols, int32_t r0, int32_t r1,
-                                   int32_t rows_per_block, float *part, int64_t ld_part,
-                                   void *hip_stream);
+/* ReLU backward in place + bias gradient, for n_planes matrices of [n_rows][n_cols]
+ * (plane z at dz + z * dz_plane_stride / a + z * a_plane_stride: the two critics'
+ * activations when they are kept in planes; 1 otherwise): dz[m][j] *= (a[m][j] > 0);
+ * part[block][z * n_cols + j] = the block's column sums of the result over its
+ * rows r0 <= m < r1 (block = rows_per_block rows; zeros for a block without such
+ * a row). */
+TTL_API int ttl_relu_backward_bias(float *dz, int64_t ld_dz, int64_t dz_plane_stride,
+                                   const float *a, int64_t lda, int64_t a_plane_stride,
+                                   int32_t n_planes, int32_t n_rows, int32_t n_cols,
+                                   int32_t r0, int32_t r1, int32_t rows_per_block,
+                                   float *part, int64_t ld_part, void *hip_stream);
 
 /* One segment of ttl_colsum_finalize: out[j] = scale * sum_{r < n_part}
  * part[r * ld + j] (+ out[j] if accumulate), j < n, summed in the fixed order
- * r = 0, 4, 8, ... | 1, 5, ... | ... then across the four. */
+ * r = 0, 4, 8, ... | 1, 5, ... | ... then across the four (n > 8), or r = 0, 32,
+ * ... | 1, 33, ... | ... then across the 32 (n <= 8). */
 typedef struct ttl_colsum_seg {
     const float *part;
     int64_t ld;

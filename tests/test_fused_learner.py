@@ -220,6 +220,11 @@ def test_thin_forward_kernels(M, H, A):
                          HEAD_PLAIN, out, 2)
         res.append(out)
     _no_worse(*res, 'block diagonal')
+    # ... and with the two networks in planes of their own [2 x M x H]
+    planes = torch.stack([a2[:, :H], a2[:, H:]]).contiguous()
+    out_p = torch.zeros(M, 2, device=DEV)
+    hip.thin_forward(planes, w[:2].contiguous(), b[:2].contiguous(), 2, True, HEAD_PLAIN, out_p, 2)
+    assert torch.equal(out_p, res[0])
 
 
 def _three(fn):
@@ -263,7 +268,16 @@ def test_backward_kernels(M, H):
         part = torch.full((R, 4 * H + 2), 7.0, device=DEV, dtype=dt)
         ops.thin_backward(dq.to(dt), a2.to(dt)[:, :2 * H], w2.to(dt), 2, True, r0, r1, dz, part)
         return dz, part
-    _check_three(_three(blockdiag), ('thin bd dz', 'thin bd slab'))
+    res_bd = _three(blockdiag)
+    _check_three(res_bd, ('thin bd dz', 'thin bd slab'))
+    # the same with activations and gradients in planes [2 x M x H]: same bits
+    from tracktolearn_amd.algorithms.shared.fused import HipOps
+    a_pl = torch.stack([a2[:, :H], a2[:, H:2 * H]]).contiguous()
+    dz_pl = torch.zeros(2, M, H, device=DEV)
+    part_pl = torch.full((R, 4 * H + 2), 7.0, device=DEV)
+    HipOps(DEV).thin_backward(dq, a_pl, w2, 2, True, r0, r1, dz_pl, part_pl)
+    assert torch.equal(torch.cat([dz_pl[0], dz_pl[1]], dim=1), res_bd[0][0])
+    assert torch.equal(part_pl, res_bd[0][1])
     # ReLU backward + bias partials
     d0 = torch.randn(M, 2 * H, generator=g).to(DEV)
 
@@ -275,6 +289,11 @@ def test_backward_kernels(M, H):
     res = _three(relu)
     assert torch.equal(res[0][0], res[1][0])
     _check_three(res, ('relu dz', 'relu slab'))
+    dz_pl = torch.stack([d0[:, :H], d0[:, H:]]).contiguous()
+    part_pl = torch.full((R, 2 * H), 7.0, device=DEV)
+    HipOps(DEV).relu_backward_bias(dz_pl, a_pl, r0, r1, part_pl)
+    assert torch.equal(torch.cat([dz_pl[0], dz_pl[1]], dim=1), res[0][0])
+    assert torch.equal(part_pl, res[0][1])
     # finalize: wide, narrow and scaled segments in one launch
     part = res[0][1]
     narrow = torch.randn(300, 8, generator=g).to(DEV)
@@ -321,14 +340,17 @@ def test_losses_adam_and_input_kernels():
                 dq = torch.zeros(2 * n, 2, **z)
                 part = torch.zeros(-(-n // LOSS_BLOCK), 8, **z)
                 steps = torch.tensor([4.0, 9.0, 0.0], **z)
+                pows = torch.tensor([0.9 ** 4, 0.999 ** 4, 0.9 ** 9, 0.999 ** 9, 1.0, 1.0],
+                                    dtype=torch.float64, device=DEV)
                 consts = torch.zeros(6, **z)
                 ops.sac_losses(q_on, q_tg, logp, r, nd, log_alpha, const, 0.99, dq, part, steps,
-                               consts, mask, 3e-4)
-                res.append((dq, part.sum(0), steps, consts))
+                               consts, pows, mask, 3e-4)
+                res.append((dq, part.sum(0), steps, consts, pows))
             assert torch.equal(res[0][2], res[1][2])
             _close(res[0][0], res[1][0], 1e-6, 1e-9, 'dq')
             _close(res[0][1], res[1][1], 1e-5, 1e-3, 'loss sums')
             _close(res[0][3], res[1][3], 1e-6, 0, 'adam scalars')
+            _close(res[0][4], res[1][4], 1e-14, 0, 'beta powers')
     # Adam + Polyak over an arena whose length is not a multiple of 4
     n = 1000003
     p0, g0 = torch.randn(n + 1, generator=g).to(DEV)[:n], torch.randn(n + 1, generator=g).to(DEV)[:n]
@@ -347,13 +369,14 @@ def test_losses_adam_and_input_kernels():
     opt = torch.optim.Adam([w], lr=3e-4)
     p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
     steps, consts = torch.zeros(1, **z), torch.zeros(2, **z)
+    pows = torch.ones(2, dtype=torch.float64, device=DEV)
     dummy = torch.zeros(2, 2, **z)
     for it in range(3):
         gi = torch.randn(n, generator=g).to(DEV)
         w.grad = gi.clone()
         opt.step()
         hip.sac_losses(dummy, dummy[:1], dummy.view(-1)[:2], dummy[0, :1], dummy[0, :1], None, 0.2,
-                       0.99, torch.zeros(2, 2, **z), None, steps, consts, 0b1, 3e-4)
+                       0.99, torch.zeros(2, 2, **z), None, steps, consts, pows, 0b1, 3e-4)
         hip.adam_polyak(p, gi, m, v, None, consts, 0.0)
     assert float(steps) == 3.0
     _close(p, w.data, 2e-7, 1e-7, 'three Adam steps vs torch.optim.Adam')     # <= 1 ulp

@@ -146,21 +146,22 @@ SYMBOLS = {
     'ttl_pack_streamlines': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_void_p, C.c_void_p]),
     # ---- include/ttl_learner.h
-    'ttl_thin_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
-                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
-                                   C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p]),
+    'ttl_thin_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttl_sac_losses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32,
-                                 C.c_double, C.c_double, C.c_double, C.c_void_p]),
-    'ttl_thin_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
-                                    C.c_int64, C.c_void_p]),
-    'ttl_relu_backward_bias': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                         C.c_void_p, C.c_int64, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    'ttl_thin_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                    C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    'ttl_relu_backward_bias': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                         C.c_int64, C.c_void_p]),
     'ttl_colsum_finalize': (C.c_int, [C.POINTER(ColsumSeg), C.c_int32, C.c_void_p]),
     'ttl_sac_actor_head_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -51,7 +51,7 @@ except AttributeError:                  # pragma: no cover
         return torch.cuda.current_stream(index).cuda_stream
 
 HEAD_PLAIN, HEAD_SAC, HEAD_TANH = 0, 1, 2
-THIN_FWD_ROWS = 16
+THIN_FWD_ROWS = 4
 LOSS_BLOCK = 256
 BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
 #: slab rows (row blocks) of the backward kernels: enough workgroups to fill
@@ -79,42 +79,58 @@ class HipOps:
     def _s(self):
         return C.c_void_p(_raw_stream(self.index))
 
+    @staticmethod
+    def _blocks(t, n_out, block_diagonal):
+        """(n_rows, n_in, row stride, block stride) of a thin layer's input: one
+        matrix [M x n_in]; or, block diagonal, n_out networks side by side
+        [M x n_out * n_in] or in planes [n_out x M x n_in]."""
+        if not block_diagonal:
+            assert t.dim() == 2 and t.stride(1) == 1
+            return t.shape[0], t.shape[1], t.stride(0), 0
+        if t.dim() == 3:
+            assert t.shape[0] == n_out and t.stride(2) == 1
+            return t.shape[1], t.shape[2], t.stride(1), t.stride(0)
+        assert t.stride(1) == 1 and t.shape[1] % n_out == 0
+        return t.shape[0], t.shape[1] // n_out, t.stride(0), t.shape[1] // n_out
+
     def thin_forward(self, a, w, b, n_out, block_diagonal, head, out, ld_out, eps=None,
                      entropy_rows=0, logp=None, ls_raw=None, ent_part=None):
-        n_rows = a.shape[0]
-        n_in = a.shape[1] // n_out if block_diagonal else a.shape[1]
-        assert a.stride(1) == 1 and w.is_contiguous() and w.numel() == n_out * n_in
+        n_rows, n_in, lda, a_bs = self._blocks(a, n_out, block_diagonal)
+        assert w.is_contiguous() and w.numel() == n_out * n_in
         _lib.check(self.lib.ttl_thin_forward(
-            _ptr(a), a.stride(0), _ptr(w), _ptr(b), n_rows, n_in, n_out, int(block_diagonal),
+            _ptr(a), lda, a_bs, _ptr(w), _ptr(b), n_rows, n_in, n_out, int(block_diagonal),
             head, _ptr(eps) if eps is not None else None, entropy_rows, _ptr(out), ld_out,
             _ptr(logp) if logp is not None else None,
             _ptr(ls_raw) if ls_raw is not None else None,
             _ptr(ent_part) if ent_part is not None else None, self._s()), 'ttl_thin_forward')
 
     def sac_losses(self, q_on, q_tg, logp, reward, not_done, log_alpha, alpha_const, gamma,
-                   dq, loss_part, steps, consts, tick_mask, lr):
+                   dq, loss_part, steps, consts, beta_pows, tick_mask, lr):
         n = reward.shape[0]
         _lib.check(self.lib.ttl_sac_losses(
             _ptr(q_on), _ptr(q_tg), _ptr(logp), _ptr(reward), _ptr(not_done), n,
             _ptr(log_alpha) if log_alpha is not None else None, float(alpha_const),
             float(gamma), _ptr(dq), _ptr(loss_part) if loss_part is not None else None,
-            _ptr(steps), _ptr(consts), steps.numel(), tick_mask, float(lr), BETA1, BETA2,
-            self._s()), 'ttl_sac_losses')
+            _ptr(steps), _ptr(consts), _ptr(beta_pows), steps.numel(), tick_mask, float(lr),
+            BETA1, BETA2, self._s()), 'ttl_sac_losses')
 
     def thin_backward(self, d_out, a, w, n_out, block_diagonal, r0, r1, dz, part):
-        n_rows = a.shape[0]
-        n_in = a.shape[1] // n_out if block_diagonal else a.shape[1]
-        assert a.stride(1) == 1 and dz.stride(1) == 1 and d_out.stride(1) == 1
+        n_rows, n_in, lda, a_bs = self._blocks(a, n_out, block_diagonal)
+        _, n_in_dz, ld_dz, dz_bs = self._blocks(dz, n_out, block_diagonal)
+        assert n_in_dz == n_in and d_out.stride(1) == 1
         _lib.check(self.lib.ttl_thin_backward(
-            _ptr(d_out), d_out.stride(0), _ptr(a), a.stride(0), _ptr(w), n_rows, n_in, n_out,
-            int(block_diagonal), r0, r1, _rows_per_block(n_rows), _ptr(dz), dz.stride(0),
+            _ptr(d_out), d_out.stride(0), _ptr(a), lda, a_bs, _ptr(w), n_rows, n_in, n_out,
+            int(block_diagonal), r0, r1, _rows_per_block(n_rows), _ptr(dz), ld_dz, dz_bs,
             _ptr(part), part.stride(0), self._s()), 'ttl_thin_backward')
 
     def relu_backward_bias(self, dz, a, r0, r1, part):
-        n_rows, n_cols = dz.shape
-        assert a.shape == dz.shape and a.stride(1) == 1 and dz.stride(1) == 1
+        """dz, a: [M x n_cols], or planes [P x M x n_cols] (slab columns P * n_cols)."""
+        assert a.shape == dz.shape and a.stride(-1) == 1 and dz.stride(-1) == 1
+        planes = dz.shape[0] if dz.dim() == 3 else 1
+        n_rows, n_cols = dz.shape[-2], dz.shape[-1]
         _lib.check(self.lib.ttl_relu_backward_bias(
-            _ptr(dz), dz.stride(0), _ptr(a), a.stride(0), n_rows, n_cols, r0, r1,
+            _ptr(dz), dz.stride(-2), dz.stride(0) if dz.dim() == 3 else 0, _ptr(a),
+            a.stride(-2), a.stride(0) if a.dim() == 3 else 0, planes, n_rows, n_cols, r0, r1,
             _rows_per_block(n_rows), _ptr(part), part.stride(0), self._s()),
             'ttl_relu_backward_bias')
 
@@ -242,6 +258,8 @@ class FusedSACUpdate:
         self._batch = None
         self.steps = torch.zeros(3, dtype=self.dtype, device=self.device)
         self.consts = torch.zeros(6, dtype=self.dtype, device=self.device)
+        #: beta1^step, beta2^step per optimizer (float64, advanced on the device)
+        self.beta_pows = torch.ones(6, dtype=torch.float64, device=self.device)
         self._bind_optimizers()
         self.loss_out = torch.zeros(8, dtype=self.dtype, device=self.device)
         self.mean_logp = torch.zeros(1, dtype=self.dtype, device=self.device)
@@ -345,7 +363,10 @@ class FusedSACUpdate:
             # state made by torch's own step() or load_state_dict(): import it
             m_view.copy_(st['exp_avg'])
             v_view.copy_(st['exp_avg_sq'])
-            self.steps[k_opt] = float(st['step'])
+            step = float(st['step'])
+            self.steps[k_opt] = step
+            self.beta_pows[2 * k_opt] = BETA1 ** step
+            self.beta_pows[2 * k_opt + 1] = BETA2 ** step
         st['step'] = self.steps[k_opt]
         st['exp_avg'] = m_view
         st['exp_avg_sq'] = v_view
@@ -376,13 +397,19 @@ class FusedSACUpdate:
         self.logp = torch.empty(2 * B, **z)
         self.ls_raw = torch.empty(2 * B, A, **z)
         self.ent_part = torch.zeros(-(-2 * B // THIN_FWD_ROWS), 1, **z)
-        self.hc = [torch.empty(2 * B, 2 * h, **z) for h in self.hq]
-        self.ht = [torch.empty(B, 2 * h, **z) for h in self.hq]
+        # the critics' activations: layer 0 side by side [rows x 2h] (one stacked
+        # GEMM), the layers above in planes [2 x rows x h] -- contiguous GEMM outputs
+        # keep the bias + ReLU epilogue (a strided `out` costs torch's addmm a bias
+        # broadcast copy and a separate ReLU pass, ~25 us per GEMM here)
+        def crit(rows):
+            return [torch.empty(rows, 2 * h, **z) if l == 0 else torch.empty(2, rows, h, **z)
+                    for l, h in enumerate(self.hq)]
+        self.hc, self.ht = crit(2 * B), crit(B)
         self.q_on = torch.empty(2 * B, 2, **z)
         self.q_tg = torch.empty(B, 2, **z)
         self.dq = torch.empty(2 * B, 2, **z)
         self.loss_part = torch.zeros(-(-B // LOSS_BLOCK), 8, **z)
-        self.dzc = [torch.empty(2 * B, 2 * h, **z) for h in self.hq]
+        self.dzc = crit(2 * B)
         self.dza = [torch.empty(B, h, **z) for h in self.ha]
         self.wa = torch.empty(A, 2 * self.hq[0], **z)
         self.d_head = torch.empty(B, 2 * A, **z)
@@ -450,11 +477,11 @@ class FusedSACUpdate:
             fused(Bv(aq, flat, 0).view(2 * h0), x, W(aq, flat, 0).view(2 * h0, S + A).t(),
                   use_gelu=False, out=hbuf[0])
             for l in range(1, L):
-                hp, h = self.hq[l - 1], self.hq[l]
+                hp = self.hq[l - 1]
                 for k in range(2):
-                    fused(Bv(aq, flat, l)[k], hbuf[l - 1][:, k * hp:(k + 1) * hp],
-                          W(aq, flat, l)[k].t(), use_gelu=False,
-                          out=hbuf[l][:, k * h:(k + 1) * h])
+                    prev = hbuf[0][:, k * hp:(k + 1) * hp] if l == 1 else hbuf[l - 1][k]
+                    fused(Bv(aq, flat, l)[k], prev, W(aq, flat, l)[k].t(), use_gelu=False,
+                          out=hbuf[l][k])
             ops.thin_forward(hbuf[L - 1], W(aq, flat, L), Bv(aq, flat, L).view(2), 2, True,
                              HEAD_PLAIN, qout, 2)
 
@@ -463,20 +490,24 @@ class FusedSACUpdate:
         ops.sac_losses(self.q_on, self.q_tg, self.logp, reward, not_done, log_alpha,
                        0.0 if self.auto else alg.alpha, alg.gamma, self.dq,
                        self.loss_part if want_losses else None, self.steps, self.consts,
-                       0b111 if self.auto else 0b110, alg.lr)
+                       self.beta_pows, 0b111 if self.auto else 0b110, alg.lr)
 
         # ---- critics backward: rows [0,B) train the critics, rows [B,2B)
         #      carry the actor loss down to pi(s)
         ops.thin_backward(self.dq, self.hc[L - 1], W(aq, aq.online, L), 2, True, 0, B,
                           self.dzc[L - 1], self.part_q_top)
         for l in range(L - 1, 0, -1):
-            hp, h = self.hq[l - 1], self.hq[l]
+            hp = self.hq[l - 1]
             for k in range(2):
-                dz = self.dzc[l][:, k * h:(k + 1) * h]
-                torch.mm(dz[:B].t(), self.hc[l - 1][:B, k * hp:(k + 1) * hp],
-                         out=W(aq, aq.grad, l)[k])
-                torch.mm(dz, W(aq, aq.online, l)[k], out=self.dzc[l - 1][:, k * hp:(k + 1) * hp])
-            if l - 1 == 0:
+                dz = self.dzc[l][k]
+                if l == 1:
+                    cols = slice(k * hp, (k + 1) * hp)
+                    a_prev, dz_prev = self.hc[0][:B, cols], self.dzc[0][:, cols]
+                else:
+                    a_prev, dz_prev = self.hc[l - 1][k][:B], self.dzc[l - 1][k]
+                torch.mm(dz[:B].t(), a_prev, out=W(aq, aq.grad, l)[k])
+                torch.mm(dz, W(aq, aq.online, l)[k], out=dz_prev)
+            if l == 1:
                 ops.relu_backward_bias(self.dzc[0][:B], self.hc[0][:B], 0, B, self.part_q[0])
             else:
                 ops.relu_backward_bias(self.dzc[l - 1], self.hc[l - 1], 0, B,

@@ -55,7 +55,7 @@ __device__ __forceinline__ float softplus_t(float x) {
 // thin forward (+ squashed-gaussian head)
 // ------------------------------------------------------------------------
 struct ThinFwd {
-    const float *a; int64_t lda;
+    const float *a; int64_t lda; int64_t a_bs;
     const float *w; const float *b;
     int n_rows, n_in;
     int head; const float *eps; int ent_rows;
@@ -63,35 +63,46 @@ struct ThinFwd {
     float *logp; float *ls_raw; float *ent_part;
 };
 
-constexpr int FWD_RW = 4;                       // rows per wave
-static_assert(FWD_RW * NW == TTL_THIN_FWD_ROWS, "block rows");
+constexpr int FWD_ROWS = TTL_THIN_FWD_ROWS;     // rows per workgroup
+static_assert(FWD_ROWS == 4, "one epilogue thread per row, 4 x NOUT combine threads");
 
+// A workgroup takes FWD_ROWS rows; its four waves split the columns (each wave
+// a contiguous quarter, rounded up to whole 64 * V chunks), so 8192 rows are
+// 8192 waves with a handful of 16-byte loads in flight each, and the thin
+// layer's weights are read once per workgroup.  Per-wave partial sums meet in
+// LDS in wave order.
 template <int NOUT, bool BD, int V>
 __global__ __launch_bounds__(LB) void k_thin_forward(ThinFwd P) {
+    __shared__ float part[NW][FWD_ROWS][NOUT];
+    __shared__ float y[FWD_ROWS][NOUT];
+    __shared__ float ent[FWD_ROWS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * TTL_THIN_FWD_ROWS + wv * FWD_RW;
-    float acc[FWD_RW][NOUT];
+    const int m0 = blockIdx.x * FWD_ROWS;
+    const int chunk = 64 * V;
+    const int per_wave = ((P.n_in + NW * chunk - 1) / (NW * chunk)) * chunk;
+    const int c_lo = wv * per_wave, c_hi = min(c_lo + per_wave, P.n_in);
+    float acc[FWD_ROWS][NOUT];
 #pragma unroll
-    for (int r = 0; r < FWD_RW; ++r)
+    for (int r = 0; r < FWD_ROWS; ++r)
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) acc[r][o] = 0.f;
-    const float *arow[FWD_RW];
+    const float *arow[FWD_ROWS];
 #pragma unroll
-    for (int r = 0; r < FWD_RW; ++r) {
+    for (int r = 0; r < FWD_ROWS; ++r) {
         const int m = min(m0 + r, P.n_rows - 1);      // clamped: loads stay in bounds
         arow[r] = P.a + (int64_t)m * P.lda;
     }
     if constexpr (!BD) {
-        for (int c = lane * V; c < P.n_in; c += 64 * V) {
-            float av[FWD_RW][V];
+        for (int c = c_lo + lane * V; c < c_hi; c += chunk) {
+            float av[FWD_ROWS][V];
 #pragma unroll
-            for (int r = 0; r < FWD_RW; ++r) ldv<V>(av[r], arow[r] + c);
+            for (int r = 0; r < FWD_ROWS; ++r) ldv<V>(av[r], arow[r] + c);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 float wq[V];
                 ldv<V>(wq, P.w + (int64_t)o * P.n_in + c);
 #pragma unroll
-                for (int r = 0; r < FWD_RW; ++r)
+                for (int r = 0; r < FWD_ROWS; ++r)
 #pragma unroll
                     for (int v = 0; v < V; ++v) acc[r][o] += av[r][v] * wq[v];
             }
@@ -99,13 +110,13 @@ __global__ __launch_bounds__(LB) void k_thin_forward(ThinFwd P) {
     } else {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
-            for (int c = lane * V; c < P.n_in; c += 64 * V) {
+            for (int c = c_lo + lane * V; c < c_hi; c += chunk) {
                 float wq[V];
                 ldv<V>(wq, P.w + (int64_t)o * P.n_in + c);
 #pragma unroll
-                for (int r = 0; r < FWD_RW; ++r) {
+                for (int r = 0; r < FWD_ROWS; ++r) {
                     float av[V];
-                    ldv<V>(av, arow[r] + (int64_t)o * P.n_in + c);
+                    ldv<V>(av, arow[r] + (int64_t)o * P.a_bs + c);
 #pragma unroll
                     for (int v = 0; v < V; ++v) acc[r][o] += av[v] * wq[v];
                 }
@@ -113,64 +124,55 @@ __global__ __launch_bounds__(LB) void k_thin_forward(ThinFwd P) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < FWD_RW; ++r)
+    for (int r = 0; r < FWD_ROWS; ++r)
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) acc[r][o] = wave_sum(acc[r][o]) + P.b[o];
-
+        for (int o = 0; o < NOUT; ++o) {
+            const float t = wave_sum(acc[r][o]);
+            if (lane == 0) part[wv][r][o] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x < FWD_ROWS * NOUT) {
+        const int r = threadIdx.x / NOUT, o = threadIdx.x - r * NOUT;
+        y[r][o] = (((part[0][r][o] + part[1][r][o]) + part[2][r][o]) + part[3][r][o]) + P.b[o];
+    }
+    __syncthreads();
+    const int r = threadIdx.x, m = m0 + r;
     if (P.head != TTL_HEAD_SAC) {
+        if (r < FWD_ROWS && m < P.n_rows) {
 #pragma unroll
-        for (int r = 0; r < FWD_RW; ++r) {
-            const int m = m0 + r;
-            if (m < P.n_rows && lane == 0) {
-#pragma unroll
-                for (int o = 0; o < NOUT; ++o) {
-                    const float y = acc[r][o];
-                    P.out[(int64_t)m * P.ld_out + o] = P.head == TTL_HEAD_TANH ? tanhf(y) : y;
-                }
-            }
+            for (int o = 0; o < NOUT; ++o)
+                P.out[(int64_t)m * P.ld_out + o] = P.head == TTL_HEAD_TANH ? tanhf(y[r][o]) : y[r][o];
         }
         return;
     }
     if constexpr (NOUT % 2 == 0 && NOUT >= 2) {
         constexpr int NA = NOUT / 2;
-        __shared__ float ent[NW];
-        float ent_wave = 0.f;
-#pragma unroll
-        for (int r = 0; r < FWD_RW; ++r) {
-            const int m = m0 + r;
-            const int mc = min(m, P.n_rows - 1);
-            float lg = 0.f, corr = 0.f, pi[NA], raw[NA];
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const float mu = acc[r][i];
-                raw[i] = acc[r][NA + i];
-                const float ls = fminf(fmaxf(raw[i], LOG_STD_MIN), LOG_STD_MAX);
-                const float sd = expf(ls);
-                const float u = mu + P.eps[(int64_t)mc * NA + i] * sd;
-                const float var = sd * sd;
-                const float d = u - mu;
-                const float g = -(d * d) / (2.f * var) - logf(sd) - HALF_LOG_2PI;
-                const float cr = 2.f * (LOG_2 - u - softplus_t(-2.f * u));
-                lg = i == 0 ? g : lg + g;
-                corr = i == 0 ? cr : corr + cr;
-                pi[i] = tanhf(u);
-            }
-            const float lp = lg - corr;
+        if (r < FWD_ROWS) {
+            float lp = 0.f;
             if (m < P.n_rows) {
-                if (m < P.ent_rows) ent_wave += lp;
-                if (lane == 0) {
-                    float *dst = P.out + (int64_t)m * P.ld_out;
+                float lg = 0.f, corr = 0.f;
+                float *dst = P.out + (int64_t)m * P.ld_out;
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) {
-                        dst[i] = pi[i];
-                        P.ls_raw[(int64_t)m * NA + i] = raw[i];
-                    }
-                    P.logp[m] = lp;
+                for (int i = 0; i < NA; ++i) {
+                    const float mu = y[r][i], raw = y[r][NA + i];
+                    const float ls = fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX);
+                    const float sd = expf(ls);
+                    const float u = mu + P.eps[(int64_t)m * NA + i] * sd;
+                    const float var = sd * sd;
+                    const float d = u - mu;
+                    const float g = -(d * d) / (2.f * var) - logf(sd) - HALF_LOG_2PI;
+                    const float cr = 2.f * (LOG_2 - u - softplus_t(-2.f * u));
+                    lg = i == 0 ? g : lg + g;
+                    corr = i == 0 ? cr : corr + cr;
+                    dst[i] = tanhf(u);
+                    P.ls_raw[(int64_t)m * NA + i] = raw;
                 }
+                lp = lg - corr;
+                P.logp[m] = lp;
             }
+            ent[r] = m < P.ent_rows && m < P.n_rows ? lp : 0.f;
         }
         if (P.ent_part) {
-            if (lane == 0) ent[wv] = ent_wave;
             __syncthreads();
             if (threadIdx.x == 0)
                 P.ent_part[blockIdx.x] = ((ent[0] + ent[1]) + ent[2]) + ent[3];
@@ -186,7 +188,7 @@ struct LossArgs {
     int n;
     const float *log_alpha; float alpha_const, gamma;
     float *dq, *loss_part;
-    float *steps, *consts; int n_opt; unsigned tick_mask;
+    float *steps, *consts; double *beta_pows; int n_opt; unsigned tick_mask;
     double lr, beta1, beta2;
 };
 
@@ -228,12 +230,13 @@ __global__ __launch_bounds__(LB) void k_sac_losses(LossArgs P) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int k = 0; k < P.n_opt; ++k) {
             if (!((P.tick_mask >> k) & 1u)) continue;
-            const float st = P.steps[k] + 1.f;
-            P.steps[k] = st;
-            const double bc1 = 1.0 - pow(P.beta1, (double)st);
-            const double bc2 = 1.0 - pow(P.beta2, (double)st);
-            P.consts[2 * k] = (float)(P.lr / bc1);
-            P.consts[2 * k + 1] = (float)sqrt(bc2);
+            P.steps[k] = P.steps[k] + 1.f;
+            // beta^step kept as running products (float64): no pow() here
+            const double p1 = P.beta_pows[2 * k] * P.beta1, p2 = P.beta_pows[2 * k + 1] * P.beta2;
+            P.beta_pows[2 * k] = p1;
+            P.beta_pows[2 * k + 1] = p2;
+            P.consts[2 * k] = (float)(P.lr / (1.0 - p1));
+            P.consts[2 * k + 1] = (float)sqrt(1.0 - p2);
         }
     }
 }
@@ -243,10 +246,10 @@ __global__ __launch_bounds__(LB) void k_sac_losses(LossArgs P) {
 // ------------------------------------------------------------------------
 struct ThinBwd {
     const float *d_out; int64_t ld_dout;
-    const float *a; int64_t lda;
+    const float *a; int64_t lda; int64_t a_bs;    // block-diagonal: network o at a + o * a_bs
     const float *w;
     int n_rows, n_in, n_cols, r0, r1, rpb;
-    float *dz; int64_t ld_dz;
+    float *dz; int64_t ld_dz; int64_t dz_bs;
     float *part; int64_t ld_part;
 };
 
@@ -283,6 +286,10 @@ __global__ __launch_bounds__(LB) void k_thin_backward(ThinBwd P) {
     const bool cok = col < P.n_cols;
     const int colc = cok ? col : 0;
     const int ob = BD ? colc / P.n_in : 0;                 // my critic (block diagonal)
+    // element (m, col) of a / dz: networks side by side in a row (bs = n_in) or
+    // in planes of their own (bs = plane size, row stride n_in)
+    const int64_t a_off = BD ? (int64_t)ob * P.a_bs + (colc - ob * P.n_in) : colc;
+    const int64_t dz_off = BD ? (int64_t)ob * P.dz_bs + (colc - ob * P.n_in) : colc;
     float wq[BD ? 1 : NOUT][V];
     if constexpr (BD) {
         ldv<V>(wq[0], P.w + colc);                         // [n_out][n_in] flat == column
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(LB) void k_thin_backward(ThinBwd P) {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) d[o] = P.d_out[(int64_t)m * P.ld_dout + o];
         float av[V], g[V];
-        ldv<V>(av, P.a + (int64_t)m * P.lda + colc);
+        ldv<V>(av, P.a + (int64_t)m * P.lda + a_off);
         float dsel = d[0];
         if constexpr (BD) {
 #pragma unroll
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(LB) void k_thin_backward(ThinBwd P) {
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) g[v] = av[v] > 0.f ? g[v] : 0.f;
-        if (cok) stv<V>(P.dz + (int64_t)m * P.ld_dz + col, g);
+        if (cok) stv<V>(P.dz + (int64_t)m * P.ld_dz + dz_off, g);
         if (m >= P.r0 && m < P.r1) {
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[0][v] += g[v];
@@ -368,8 +375,8 @@ __global__ __launch_bounds__(LB) void k_thin_backward(ThinBwd P) {
 }
 
 struct ReluBwd {
-    float *dz; int64_t ld_dz;
-    const float *a; int64_t lda;
+    float *dz; int64_t ld_dz; int64_t dz_ps;      // plane z at dz + z * dz_ps
+    const float *a; int64_t lda; int64_t a_ps;
     int n_rows, n_cols, r0, r1, rpb;
     float *part; int64_t ld_part;
 };
@@ -382,6 +389,8 @@ __global__ __launch_bounds__(LB) void k_relu_backward_bias(ReluBwd P) {
     const int col = col0 + lane * V;
     const bool cok = col < P.n_cols;
     const int colc = cok ? col : 0;
+    float *dz = P.dz + (int64_t)blockIdx.z * P.dz_ps;
+    const float *a = P.a + (int64_t)blockIdx.z * P.a_ps;
     float acc[1][V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[0][v] = 0.f;
@@ -391,17 +400,18 @@ __global__ __launch_bounds__(LB) void k_relu_backward_bias(ReluBwd P) {
         const int m = mb + i;
         if (m >= P.n_rows) break;
         float av[V], g[V];
-        ldv<V>(av, P.a + (int64_t)m * P.lda + colc);
-        ldv<V>(g, P.dz + (int64_t)m * P.ld_dz + colc);
+        ldv<V>(av, a + (int64_t)m * P.lda + colc);
+        ldv<V>(g, dz + (int64_t)m * P.ld_dz + colc);
 #pragma unroll
         for (int v = 0; v < V; ++v) g[v] = av[v] > 0.f ? g[v] : 0.f;
         if (m >= P.r0 && m < P.r1) {
 #pragma unroll
             for (int v = 0; v < V; ++v) acc[0][v] += g[v];
         }
-        if (cok) stv<V>(P.dz + (int64_t)m * P.ld_dz + col, g);
+        if (cok) stv<V>(dz + (int64_t)m * P.ld_dz + col, g);
     }
-    const int64_t off[1] = {0};
+    // plane z owns the columns [z * n_cols, (z + 1) * n_cols) of the slab row
+    const int64_t off[1] = {(int64_t)blockIdx.z * P.n_cols};
     block_reduce_store<1, V>(lds, acc, P.part + (int64_t)blockIdx.y * P.ld_part, off, col0,
                              P.n_cols);
 }
@@ -436,23 +446,23 @@ __global__ __launch_bounds__(LB) void k_colsum_finalize(Segs S) {
         }
         return;
     }
-    // narrow segment (scalars: loss terms, thin-layer bias grads): the rows
-    // over the threads, a fixed tree over the block
-    for (int c = 0; c < sg.n; ++c) {
+    // narrow segment (scalars: loss terms, thin-layer bias grads; n <= 8): thread
+    // t sums the rows r = t / 8, t / 8 + 32, ... of column t % 8, then one thread
+    // per column adds the 32 partial sums in order
+    {
+        const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
         float acc = 0.f;
-        for (int r = threadIdx.x; r < sg.n_part; r += LB) acc += sg.part[(int64_t)r * sg.ld + c];
+        if (c < sg.n)
+            for (int r = g; r < sg.n_part; r += LB / 8) acc += sg.part[(int64_t)r * sg.ld + c];
         lds[threadIdx.x] = acc;
         __syncthreads();
-        for (int h = LB / 2; h > 0; h >>= 1) {
-            if ((int)threadIdx.x < h) lds[threadIdx.x] += lds[threadIdx.x + h];
-            __syncthreads();
+        if ((int)threadIdx.x < sg.n) {
+            float t = lds[threadIdx.x];
+            for (int k = 1; k < LB / 8; ++k) t += lds[k * 8 + threadIdx.x];
+            t *= sg.scale;
+            if (sg.accumulate) t += sg.out[threadIdx.x];
+            sg.out[threadIdx.x] = t;
         }
-        if (threadIdx.x == 0) {
-            float t = lds[0] * sg.scale;
-            if (sg.accumulate) t += sg.out[c];
-            sg.out[c] = t;
-        }
-        __syncthreads();
     }
 }
 
@@ -471,24 +481,29 @@ struct HeadBwd {
 
 template <int NA, int V>
 __global__ __launch_bounds__(LB) void k_sac_actor_head_backward(HeadBwd P) {
+    // as k_thin_forward: FWD_ROWS rows per workgroup, the columns split over its waves
+    __shared__ float part[NW][FWD_ROWS][NA];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * (NW * FWD_RW) + wv * FWD_RW;
-    float acc[FWD_RW][NA];
+    const int m0 = blockIdx.x * FWD_ROWS;
+    const int chunk = 64 * V;
+    const int per_wave = ((P.n_cols + NW * chunk - 1) / (NW * chunk)) * chunk;
+    const int c_lo = wv * per_wave, c_hi = min(c_lo + per_wave, P.n_cols);
+    float acc[FWD_ROWS][NA];
 #pragma unroll
-    for (int r = 0; r < FWD_RW; ++r)
+    for (int r = 0; r < FWD_ROWS; ++r)
 #pragma unroll
         for (int i = 0; i < NA; ++i) acc[r][i] = 0.f;
-    const float *hrow[FWD_RW], *drow[FWD_RW];
+    const float *hrow[FWD_ROWS], *drow[FWD_ROWS];
 #pragma unroll
-    for (int r = 0; r < FWD_RW; ++r) {
+    for (int r = 0; r < FWD_ROWS; ++r) {
         const int m = min(m0 + r, P.n_rows - 1);
         hrow[r] = P.h + (int64_t)m * P.ld_h;
         drow[r] = P.dh + (int64_t)m * P.ld_dh;
     }
-    for (int c = lane * V; c < P.n_cols; c += 64 * V) {
-        float g[FWD_RW][V];
+    for (int c = c_lo + lane * V; c < c_hi; c += chunk) {
+        float g[FWD_ROWS][V];
 #pragma unroll
-        for (int r = 0; r < FWD_RW; ++r) {
+        for (int r = 0; r < FWD_ROWS; ++r) {
             float hv[V];
             ldv<V>(hv, hrow[r] + c);
             ldv<V>(g[r], drow[r] + c);
@@ -500,34 +515,32 @@ __global__ __launch_bounds__(LB) void k_sac_actor_head_backward(HeadBwd P) {
             float wq[V];
             ldv<V>(wq, P.wa + (int64_t)i * P.n_cols + c);
 #pragma unroll
-            for (int r = 0; r < FWD_RW; ++r)
+            for (int r = 0; r < FWD_ROWS; ++r)
 #pragma unroll
                 for (int v = 0; v < V; ++v) acc[r][i] += g[r][v] * wq[v];
         }
     }
 #pragma unroll
-    for (int r = 0; r < FWD_RW; ++r)
+    for (int r = 0; r < FWD_ROWS; ++r)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) acc[r][i] = wave_sum(acc[r][i]);
+        for (int i = 0; i < NA; ++i) {
+            const float t = wave_sum(acc[r][i]);
+            if (lane == 0) part[wv][r][i] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x >= FWD_ROWS * NA) return;
+    const int r = threadIdx.x / NA, i = threadIdx.x - r * NA, m = m0 + r;
+    if (m >= P.n_rows) return;
+    const float dpi = ((part[0][r][i] + part[1][r][i]) + part[2][r][i]) + part[3][r][i];
     const float alpha = P.log_alpha ? expf(P.log_alpha[0]) : P.alpha_const;
     const float an = alpha / (float)P.n_rows;
-#pragma unroll
-    for (int r = 0; r < FWD_RW; ++r) {
-        const int m = m0 + r;
-        if (m < P.n_rows && lane == 0) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const float t = P.pi[(int64_t)m * P.ld_pi + i];
-                const float du = an * (2.f * t) + acc[r][i] * (1.f - t * t);
-                const float raw = P.ls_raw[(int64_t)m * NA + i];
-                const bool in = raw >= LOG_STD_MIN && raw <= LOG_STD_MAX;
-                const float sd = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
-                P.d_head[(int64_t)m * 2 * NA + i] = du;
-                P.d_head[(int64_t)m * 2 * NA + NA + i] =
-                    in ? du * (P.eps[(int64_t)m * NA + i] * sd) - an : 0.f;
-            }
-        }
-    }
+    const float t = P.pi[(int64_t)m * P.ld_pi + i];
+    const float du = an * (2.f * t) + dpi * (1.f - t * t);
+    const float raw = P.ls_raw[(int64_t)m * NA + i];
+    const bool in = raw >= LOG_STD_MIN && raw <= LOG_STD_MAX;
+    const float sd = expf(fminf(fmaxf(raw, LOG_STD_MIN), LOG_STD_MAX));
+    P.d_head[(int64_t)m * 2 * NA + i] = du;
+    P.d_head[(int64_t)m * 2 * NA + NA + i] = in ? du * (P.eps[(int64_t)m * NA + i] * sd) - an : 0.f;
 }
 
 // ------------------------------------------------------------------------
@@ -641,16 +654,19 @@ inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 extern "C" {
 
-int ttl_thin_forward(const float *a, int64_t lda, const float *w, const float *b,
-                     int32_t n_rows, int32_t n_in, int32_t n_out, int32_t block_diagonal,
-                     int32_t head, const float *eps, int32_t entropy_rows, float *out,
+int ttl_thin_forward(const float *a, int64_t lda, int64_t a_block_stride, const float *w,
+                     const float *b, int32_t n_rows, int32_t n_in, int32_t n_out,
+                     int32_t block_diagonal, int32_t head, const float *eps, int32_t entropy_rows, float *out,
                      int64_t ld_out, float *logp, float *log_std_raw, float *entropy_part,
                      void *hip_stream) {
     if (!a || !w || !b || !out || n_rows <= 0 || n_in <= 0)
         return fail(TTL_ERR_INVALID, "ttl_thin_forward: null pointer or empty shape");
-    const int64_t width = block_diagonal ? (int64_t)n_out * n_in : n_in;
-    if (lda < width) return fail(TTL_ERR_INVALID, "ttl_thin_forward: lda %lld < %lld",
-                                 (long long)lda, (long long)width);
+    if (lda < n_in || (block_diagonal && a_block_stride < n_in))
+        return fail(TTL_ERR_INVALID, "ttl_thin_forward: lda %lld / block stride %lld < n_in %d",
+                    (long long)lda, (long long)a_block_stride, n_in);
+    if (block_diagonal && a_block_stride < lda && lda < (int64_t)n_out * a_block_stride)
+        return fail(TTL_ERR_INVALID, "ttl_thin_forward: side-by-side networks need lda >= "
+                                     "n_out * block stride");
     if (head == TTL_HEAD_SAC) {
         if (block_diagonal || (n_out != 2 && n_out != 4 && n_out != 6 && n_out != 8))
             return fail(TTL_ERR_INVALID, "ttl_thin_forward: SAC head needs a dense layer of "
@@ -664,9 +680,11 @@ int ttl_thin_forward(const float *a, int64_t lda, const float *w, const float *b
     } else if (ld_out < n_out) {
         return fail(TTL_ERR_INVALID, "ttl_thin_forward: output stride too small");
     }
-    ThinFwd P{a, lda, w, b, n_rows, n_in, head, eps, entropy_rows, out, ld_out,
-              logp, log_std_raw, head == TTL_HEAD_SAC ? entropy_part : nullptr};
-    const bool vec = n_in % 4 == 0 && lda % 4 == 0 && aligned16(a) && aligned16(w);
+    ThinFwd P{a, lda, block_diagonal ? a_block_stride : 0, w, b, n_rows, n_in, head, eps,
+              entropy_rows, out, ld_out, logp, log_std_raw,
+              head == TTL_HEAD_SAC ? entropy_part : nullptr};
+    const bool vec = n_in % 4 == 0 && lda % 4 == 0 && aligned16(a) && aligned16(w) &&
+                     (!block_diagonal || a_block_stride % 4 == 0);
     const dim3 grid((n_rows + TTL_THIN_FWD_ROWS - 1) / TTL_THIN_FWD_ROWS), block(LB);
     hipStream_t s = S(hip_stream);
 #define FWD_CASE(N, BDV)                                                                  \
@@ -686,36 +704,39 @@ int ttl_thin_forward(const float *a, int64_t lda, const float *w, const float *b
 int ttl_sac_losses(const float *q_online, const float *q_target, const float *logp,
                    const float *reward, const float *not_done, int32_t n,
                    const float *log_alpha, float alpha_const, float gamma, float *dq,
-                   float *loss_part, float *steps, float *adam_consts, int32_t n_opt,
-                   uint32_t tick_mask, double lr, double beta1, double beta2,
+                   float *loss_part, float *steps, float *adam_consts, double *beta_pows,
+                   int32_t n_opt, uint32_t tick_mask, double lr, double beta1, double beta2,
                    void *hip_stream) {
     if (!q_online || !q_target || !logp || !reward || !not_done || !dq || n <= 0)
         return fail(TTL_ERR_INVALID, "ttl_sac_losses: null pointer or empty batch");
-    if (n_opt < 0 || n_opt > 8 || (n_opt && (!steps || !adam_consts)))
+    if (n_opt < 0 || n_opt > 8 || (n_opt && (!steps || !adam_consts || !beta_pows)))
         return fail(TTL_ERR_INVALID, "ttl_sac_losses: bad optimizer table");
     LossArgs P{q_online, q_target, logp, reward, not_done, n, log_alpha, alpha_const, gamma,
-               dq, loss_part, steps, adam_consts, n_opt, tick_mask, lr, beta1, beta2};
+               dq, loss_part, steps, adam_consts, beta_pows, n_opt, tick_mask, lr, beta1, beta2};
     k_sac_losses<<<dim3((n + LB - 1) / LB), dim3(LB), 0, S(hip_stream)>>>(P);
     LAUNCH_CHECK("k_sac_losses");
     return TTL_OK;
 }
 
 int ttl_thin_backward(const float *d_out, int64_t ld_dout, const float *a, int64_t lda,
-                      const float *w, int32_t n_rows, int32_t n_in, int32_t n_out,
-                      int32_t block_diagonal, int32_t r0, int32_t r1, int32_t rows_per_block,
-                      float *dz, int64_t ld_dz, float *part, int64_t ld_part,
-                      void *hip_stream) {
+                      int64_t a_block_stride, const float *w, int32_t n_rows, int32_t n_in,
+                      int32_t n_out, int32_t block_diagonal, int32_t r0, int32_t r1,
+                      int32_t rows_per_block, float *dz, int64_t ld_dz, int64_t dz_block_stride,
+                      float *part, int64_t ld_part, void *hip_stream) {
     if (!d_out || !a || !w || !dz || !part || n_rows <= 0 || n_in <= 0 || rows_per_block <= 0)
         return fail(TTL_ERR_INVALID, "ttl_thin_backward: null pointer or empty shape");
     if (a == dz) return fail(TTL_ERR_INVALID, "ttl_thin_backward: a and dz alias");
     const int64_t n_cols = block_diagonal ? (int64_t)n_out * n_in : n_in;
-    if (lda < n_cols || ld_dz < n_cols || ld_dout < n_out ||
-        ld_part < n_cols + (int64_t)n_out * n_in + n_out)
+    if (lda < n_in || ld_dz < n_in || ld_dout < n_out ||
+        ld_part < n_cols + (int64_t)n_out * n_in + n_out ||
+        (block_diagonal && (a_block_stride < n_in || dz_block_stride < n_in)))
         return fail(TTL_ERR_INVALID, "ttl_thin_backward: a stride is too small");
-    ThinBwd P{d_out, ld_dout, a, lda, w, n_rows, n_in, (int)n_cols, r0, r1, rows_per_block,
-              dz, ld_dz, part, ld_part};
+    if (!block_diagonal) a_block_stride = dz_block_stride = 0;
+    ThinBwd P{d_out, ld_dout, a, lda, a_block_stride, w, n_rows, n_in, (int)n_cols, r0, r1,
+              rows_per_block, dz, ld_dz, dz_block_stride, part, ld_part};
     const bool vec = n_in % 4 == 0 && lda % 4 == 0 && ld_dz % 4 == 0 && aligned16(a) &&
-                     aligned16(dz) && aligned16(w);
+                     aligned16(dz) && aligned16(w) && a_block_stride % 4 == 0 &&
+                     dz_block_stride % 4 == 0;
     const int V = vec ? 4 : 1;
     const dim3 grid((unsigned)((n_cols + 64 * V - 1) / (64 * V)),
                     (unsigned)((n_rows + rows_per_block - 1) / rows_per_block)), block(LB);
@@ -734,20 +755,24 @@ int ttl_thin_backward(const float *d_out, int64_t ld_dout, const float *a, int64
                 block_diagonal ? "block diagonal" : "dense");
 }
 
-int ttl_relu_backward_bias(float *dz, int64_t ld_dz, const float *a, int64_t lda,
+int ttl_relu_backward_bias(float *dz, int64_t ld_dz, int64_t dz_plane_stride, const float *a,
+                           int64_t lda, int64_t a_plane_stride, int32_t n_planes,
                            int32_t n_rows, int32_t n_cols, int32_t r0, int32_t r1,
                            int32_t rows_per_block, float *part, int64_t ld_part,
                            void *hip_stream) {
-    if (!dz || !a || !part || n_rows <= 0 || n_cols <= 0 || rows_per_block <= 0)
+    if (!dz || !a || !part || n_rows <= 0 || n_cols <= 0 || rows_per_block <= 0 ||
+        n_planes < 1 || n_planes > 64)
         return fail(TTL_ERR_INVALID, "ttl_relu_backward_bias: null pointer or empty shape");
-    if (ld_dz < n_cols || lda < n_cols || ld_part < n_cols)
+    if (ld_dz < n_cols || lda < n_cols || ld_part < (int64_t)n_planes * n_cols)
         return fail(TTL_ERR_INVALID, "ttl_relu_backward_bias: a stride is too small");
-    ReluBwd P{dz, ld_dz, a, lda, n_rows, n_cols, r0, r1, rows_per_block, part, ld_part};
+    ReluBwd P{dz, ld_dz, dz_plane_stride, a, lda, a_plane_stride, n_rows, n_cols, r0, r1,
+              rows_per_block, part, ld_part};
     const bool vec = n_cols % 4 == 0 && lda % 4 == 0 && ld_dz % 4 == 0 && aligned16(a) &&
-                     aligned16(dz);
+                     aligned16(dz) && dz_plane_stride % 4 == 0 && a_plane_stride % 4 == 0;
     const int V = vec ? 4 : 1;
     const dim3 grid((unsigned)((n_cols + 64 * V - 1) / (64 * V)),
-                    (unsigned)((n_rows + rows_per_block - 1) / rows_per_block)), block(LB);
+                    (unsigned)((n_rows + rows_per_block - 1) / rows_per_block),
+                    (unsigned)n_planes), block(LB);
     if (vec) k_relu_backward_bias<4><<<grid, block, 0, S(hip_stream)>>>(P);
     else k_relu_backward_bias<1><<<grid, block, 0, S(hip_stream)>>>(P);
     LAUNCH_CHECK("k_relu_backward_bias");
@@ -787,7 +812,7 @@ int ttl_sac_actor_head_backward(const float *dh, int64_t ld_dh, const float *h, 
               alpha_const, d_head};
     const bool vec = n_cols % 4 == 0 && ld_dh % 4 == 0 && ld_h % 4 == 0 && aligned16(dh) &&
                      aligned16(h) && aligned16(wa);
-    const dim3 grid((n_rows + NW * FWD_RW - 1) / (NW * FWD_RW)), block(LB);
+    const dim3 grid((n_rows + FWD_ROWS - 1) / FWD_ROWS), block(LB);
     hipStream_t s = S(hip_stream);
 #define HB_CASE(N)                                                                        \
     if (n_act == N) {                                                                     \

@@ -728,9 +728,12 @@ class TrackingEnvironment(BaseEnv):
             fr = None
         if fr is not None and max_policy_us is not None and fr.policy_us > max_policy_us:
             return None         # a replayed graph would lose to the shrinking batches
-        _lib.check(self._lib.ttl_env_freerun_begin(
-            self._handle, self._host_counts.data_ptr(), self._stream()),
-            'ttl_env_freerun_begin')
+        rc = self._lib.ttl_env_freerun_begin(
+            self._handle, self._host_counts.data_ptr(), self._stream())
+        if rc == _lib.ERR_UNSUPPORTED:
+            return None         # the library has no free-running path here: the caller
+            #                     keeps its step-by-step loop (as for a slow policy)
+        _lib.check(rc, 'ttl_env_freerun_begin')
         try:
             if fr is None:      # buffers + one timing of the policy on n rows (the policy
                 # may itself read the free-running words: timed after begin)
