@@ -213,9 +213,10 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
             state, _ = env.harvest()
         return state, n
 
-    # fill the ring, first-call costs, graph capture
+    # fill the ring, first-call costs, graph capture; with the oracle a whole
+    # untimed episode (its GEMM shapes follow the number of rows scored)
     state = reset()
-    for _ in range(4):
+    for _ in range(steps if oracle else 4):
         state, _ = one_step(state)
     # SACAuto.update alone
     b = alg.replay_buffer.sample(batch)

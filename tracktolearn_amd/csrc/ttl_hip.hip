@@ -1456,6 +1456,8 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
                                                      ? TTL_FUSE_MAX_BLOCKS * BLOCK : rows;
     }
     e->local_sort = 1;
+    P.persist_rows = 0;
+    if (const char *v = getenv("TTL_GATHER_PERSIST_ROWS")) P.persist_rows = atoi(v);
     e->tail_fused = 1;
     if (const char *v = getenv("TTL_TAIL_FUSED")) e->tail_fused = atoi(v);
     e->tail_fused_max = 262144;

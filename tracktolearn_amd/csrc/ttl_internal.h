@@ -70,6 +70,7 @@ struct EnvParams {
     int xcd_rot;       // XCD x gathers range (x + xcd_rot) & 7 of the processing order
     int *counts;       // {n_continue, n_stopped}; 64 ints: the free-running step's words live here too
     int fuse_max_rows; // largest batch of the one-launch step tail (TTL_FUSE_MAX_ROWS, <= TTL_FUSE_MAX_BLOCKS * 256)
+    int persist_rows;  // gathers of at most this many rows run as one resident round (TTL_GATHER_PERSIST_ROWS, 0 = off)
 };
 
 // the one-launch tail scans at most this many per-block counts (one wave, four per lane)

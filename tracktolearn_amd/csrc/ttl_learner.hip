@@ -21,11 +21,27 @@ constexpr float HALF_LOG_2PI = 0.91893853320467274178f;   // log(sqrt(2 pi))
 constexpr float LOG_2 = 0.69314718055994530942f;
 constexpr float LOG_STD_MIN = -20.f, LOG_STD_MAX = 2.f;
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    // v + (v of the lane CTRL selects; 0 where it selects none / the row is masked)
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(t);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-    // xor butterfly: every lane ends with the same bits (a + b == b + a)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    // 64-lane sum on the VALU's DPP path (no LDS crossbar: a ds_bpermute
+    // butterfly of the 24 sums a thin layer makes per wave costs more than its
+    // loads): prefix sums inside each row of 16 lanes (row_shr 1, 2, 4, 8),
+    // then lane 15 of a row into the next row (row_bcast:15, rows 1 and 3),
+    // lane 31 into rows 2 and 3 (row_bcast:31); lane 63 holds the total.
+    // Fixed order: the same bits on every launch.  Wave-uniform result.
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <int V>
@@ -434,8 +450,19 @@ __global__ __launch_bounds__(LB) void k_colsum_finalize(Segs S) {
     if (sg.n > 8) {
         const int col = (blockIdx.x - S.first_block[k]) * 64 + lane;
         float acc = 0.f;
-        if (col < sg.n)
-            for (int r = wv; r < sg.n_part; r += NW) acc += sg.part[(int64_t)r * sg.ld + col];
+        if (col < sg.n) {
+            // eight independent loads in flight, summed in row order
+            const float *src = sg.part + col;
+            int r = wv;
+            for (; r + 7 * NW < sg.n_part; r += 8 * NW) {
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = src[(int64_t)(r + k * NW) * sg.ld];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += x[k];
+            }
+            for (; r < sg.n_part; r += NW) acc += src[(int64_t)r * sg.ld];
+        }
         lds[threadIdx.x] = acc;
         __syncthreads();
         if (wv == 0 && col < sg.n) {

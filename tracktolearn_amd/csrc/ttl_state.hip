@@ -419,69 +419,76 @@ template <int LPS, int MINW, bool LOOP, bool MERGE_TAIL>
 __global__ __launch_bounds__(BLOCK, MINW) void k_state_dd(
     EnvParams P, const int *__restrict__ idx, const int *__restrict__ row_dest,
     const int *__restrict__ proc, int n_rows, int L, float *__restrict__ out,
-    long long pitch) {
+    long long pitch, int n_vblocks) {
     // LPS lanes per streamline, 64 / LPS streamlines per wave (LPS need not be
     // a power of two: with 12 float4 columns per record a wave serves 5
     // streamlines on 60 lanes instead of 4 on 48)
     constexpr int GPW = 64 / LPS;
     constexpr int ROWS = (BLOCK / 64) * GPW;
-    int blk = blockIdx.x;
-    if (proc && P.xcd_remap) {
-        // workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
-        // share one; speed only, never correctness): give every XCD one
-        // contiguous range of the spatially sorted processing order, so that
-        // a voxel is fetched into ONE XCD's L2 instead of all eight.
-        // Bijective for any grid size (cdna_hip_programming.md, T1).
-        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = blk & 7;
-        if (P.xcd_rot == 0) {
-            blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blk >> 3);
-        } else {
-            // XCD x takes range (x + rot) & 7 of the order; a range has as many
-            // workgroups as its XCD receives (q or q + 1), so the map stays
-            // bijective for any grid size
-            const int mine = (xcd + P.xcd_rot) & 7;
-            int start = 0;
-            for (int r = 0; r < mine; ++r) start += q + ((((r - P.xcd_rot) & 7) < rr) ? 1 : 0);
-            blk = start + (blk >> 3);
-        }
-    }
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPS;
-    const int slot = blk * ROWS + (threadIdx.x >> 6) * GPW + grp;
     const int sub = lane - grp * LPS;
-    if (grp >= GPW || slot >= n_rows) return;
-    int row, g, r;
-    float px, py, pz;
-    const bool slot_records = proc && idx && P.slot_rec;   // a step in processing order
-    if (slot_records) {     // k_proc_scatter resolved row, idx[row], row_dest[row]
-        const float4 hp = *reinterpret_cast<const float4 *>(P.slot_head + 4 * (size_t)slot);
-        px = hp.x;
-        py = hp.y;
-        pz = hp.z;
-        g = __float_as_int(hp.w);
-        r = P.slot_dest[slot];
-        row = 0;
-        if (r < 0) return;      // a hole of the uncompacted order (k_tail): nothing to gather
-    } else {
-        row = proc ? proc[slot] : slot;
-        if (row < 0) return;    // a hole of an uncompacted processing order
-        g = idx ? idx[row] : row;
-        r = row_dest ? row_dest[row] : row;
+    if (grp >= GPW) return;
+    // n_vblocks == gridDim.x: one workgroup per block of ROWS slots.  A launch
+    // with fewer workgroups (TTL_GATHER_PERSIST_ROWS: one resident round) walks
+    // the blocks with a stride of gridDim.x.
+    for (int vb = blockIdx.x; vb < n_vblocks; vb += gridDim.x) {
+        int blk = vb;
+        if (proc && P.xcd_remap) {
+            // workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
+            // share one; speed only, never correctness): give every XCD one
+            // contiguous range of the spatially sorted processing order, so that
+            // a voxel is fetched into ONE XCD's L2 instead of all eight.
+            // Bijective for any grid size (cdna_hip_programming.md, T1).
+            const int nwg = n_vblocks, q = nwg >> 3, rr = nwg & 7, xcd = blk & 7;
+            if (P.xcd_rot == 0) {
+                blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (blk >> 3);
+            } else {
+                // XCD x takes range (x + rot) & 7 of the order; a range has as many
+                // workgroups as its XCD receives (q or q + 1), so the map stays
+                // bijective for any grid size
+                const int mine = (xcd + P.xcd_rot) & 7;
+                int start = 0;
+                for (int r = 0; r < mine; ++r)
+                    start += q + ((((r - P.xcd_rot) & 7) < rr) ? 1 : 0);
+                blk = start + (blk >> 3);
+            }
+        }
+        const int slot = blk * ROWS + (threadIdx.x >> 6) * GPW + grp;
+        if (slot >= n_rows) continue;
+        int row, g, r;
+        float px, py, pz;
+        const bool slot_records = proc && idx && P.slot_rec;   // a step in processing order
+        if (slot_records) {     // k_proc_scatter resolved row, idx[row], row_dest[row]
+            const float4 hp = *reinterpret_cast<const float4 *>(P.slot_head + 4 * (size_t)slot);
+            px = hp.x;
+            py = hp.y;
+            pz = hp.z;
+            g = __float_as_int(hp.w);
+            r = P.slot_dest[slot];
+            row = 0;
+            if (r < 0) continue;    // a hole of the uncompacted order (k_tail): nothing to gather
+        } else {
+            row = proc ? proc[slot] : slot;
+            if (row < 0) continue;  // a hole of an uncompacted processing order
+            g = idx ? idx[row] : row;
+            r = row_dest ? row_dest[row] : row;
+        }
+        const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
+        if (slot_records) {
+        } else if (idx) {      // a step: k_advance left the new point in row order
+            const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
+            px = hp.x;
+            py = hp.y;
+            pz = hp.z;
+        } else {        // reset: the seed
+            px = h[(L - 1) * 3 + 0];
+            py = h[(L - 1) * 3 + 1];
+            pz = h[(L - 1) * 3 + 2];
+        }
+        state_row_dd<LPS, LOOP, MERGE_TAIL>(P, px, py, pz, h, L, sub,
+                                            out + (size_t)r * (size_t)pitch);
     }
-    const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
-    if (slot_records) {
-    } else if (idx) {      // a step: k_advance left the new point in row order
-        const float4 hp = *reinterpret_cast<const float4 *>(P.head + 4 * (size_t)row);
-        px = hp.x;
-        py = hp.y;
-        pz = hp.z;
-    } else {        // reset: the seed
-        px = h[(L - 1) * 3 + 0];
-        py = h[(L - 1) * 3 + 1];
-        pz = h[(L - 1) * 3 + 2];
-    }
-    state_row_dd<LPS, LOOP, MERGE_TAIL>(P, px, py, pz, h, L, sub,
-                                        out + (size_t)r * (size_t)pitch);
 }
 
 // ---------------------------------------------------------------------------
@@ -670,7 +677,14 @@ int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx
 #define TTL_LAUNCH_STATE(LPS)                                                 \
     do {                                                                      \
         const int rows_per_block = (BLOCK / 64) * (64 / LPS);                 \
-        const dim3 grid((n_rows + rows_per_block - 1) / rows_per_block);      \
+        const int n_vb = (n_rows + rows_per_block - 1) / rows_per_block;      \
+        /* TTL_GATHER_PERSIST_ROWS (experiment, off by default): batches of at */ \
+        /* most that many rows that need more than one resident round (4       */ \
+        /* workgroups per CU x 256 CUs) run as ONE round of workgroups that    */ \
+        /* walk the blocks with a stride                                       */ \
+        const int resident = 1024;                                            \
+        const bool persist = dedupe && n_rows <= P.persist_rows && n_vb > resident; \
+        const dim3 grid(persist ? resident : n_vb);                           \
         if (!dedupe)                                                          \
             hipLaunchKernelGGL((k_state<LPS>), grid, dim3(BLOCK), 0, s, P, \
                                idx, row_dest, proc, n_rows, L, out,           \
@@ -678,11 +692,11 @@ int ttl_detail_launch_state(const EnvParams &P, int state_kernel, const int *idx
         else if (LPS < 32 && P.n_coef >= 4 && state_kernel != 3)    \
             hipLaunchKernelGGL((k_state_dd<LPS, 4, (LPS >= 32), (LPS < 32)>), grid, dim3(BLOCK), 0, s, \
                                P, idx, row_dest, proc, n_rows, L, out,   \
-                               (long long)pitch);                             \
+                               (long long)pitch, n_vb);                       \
         else                                                                  \
             hipLaunchKernelGGL((k_state_dd<LPS, (LPS >= 32 ? 2 : 4), (LPS >= 32), false>), grid, dim3(BLOCK), 0, s, \
                                P, idx, row_dest, proc, n_rows, L, out,   \
-                               (long long)pitch);                             \
+                               (long long)pitch, n_vb);                       \
     } while (0)
     if (C4 <= 4) TTL_LAUNCH_STATE(4);
     else if (C4 <= 8) TTL_LAUNCH_STATE(8);

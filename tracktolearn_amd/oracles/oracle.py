@@ -76,6 +76,15 @@ class OracleSingleton:
         self.batch_size = batch_size
         self.device = torch.device(device)
         self.drop_tail = True
+        #: on the GPU a batch is padded with zero rows to a multiple of this many
+        #: rows (0: never): the number of rows scored changes at every step (the
+        #: streamlines that just stopped / are still active), and every new row
+        #: count is a new set of GEMM shapes for which hipBLASLt picks kernels
+        #: afresh; with 512-row buckets a 4 096-row batch size has 8 shapes.
+        #: Rows are independent inside the network (attention stays inside a
+        #: streamline), so the scores of the real rows do not depend on the padding.
+        self.pad_rows = 512 if self.device.type == 'cuda' else 0
+        self._pad_buf = None
         # the resampler is the HIP kernel; CPU-only tests of the batching
         # logic inject the PyTorch restatement from tests/
         self._resample = resample if resample is not None else resample_streamlines
@@ -110,6 +119,16 @@ class OracleSingleton:
         for lo, hi in spans:
             data = self._resample(points[lo:hi], lengths[lo:hi], 128)
             dirs = (data[:, 1:] - data[:, :-1]).float()
+            rows = hi - lo
+            padded = -(-rows // self.pad_rows) * self.pad_rows if self.pad_rows else rows
+            if padded != rows:
+                if self._pad_buf is None or self._pad_buf.shape[0] < padded or \
+                        self._pad_buf.shape[1:] != dirs.shape[1:]:
+                    self._pad_buf = torch.zeros((max(padded, bs),) + tuple(dirs.shape[1:]),
+                                                dtype=dirs.dtype, device=dirs.device)
+                self._pad_buf[:rows].copy_(dirs)
+                self._pad_buf[rows:padded].zero_()
+                dirs = self._pad_buf[:padded]
             with autocast, torch.no_grad():
-                result[lo:hi] = self.model(dirs).float()
+                result[lo:hi] = self.model(dirs).float()[:rows]
         return result
