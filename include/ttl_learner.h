@@ -207,6 +207,24 @@ TTL_API int ttl_build_learner_inputs(const float *state, int64_t ld_s, const flo
                                      int64_t ld, const float *w1, int64_t ld_w1,
                                      int32_t n_w1_rows, float *wa, void *hip_stream);
 
+/* OffPolicyReplayBuffer.sample (TrackToLearn/algorithms/shared/replay.py:94-143:
+ * `ind = torch.randperm(size)[:batch]`, five `index_select`s) in one launch:
+ * `batch` (<= size) DISTINCT ring rows drawn uniformly and gathered into the
+ * five output tensors.  Instead of permuting all `size` rows (a 10^6-key sort
+ * per training step) position j of a keyed pseudo-random permutation of
+ * [0, size) is evaluated for j < batch only: a six-round balanced Feistel
+ * network over the next even power of two, cycle-walked into the range.  The
+ * caller draws (key0, key1) from its generator at every call.  state /
+ * next_state: [size][n_state], action: [size][n_act], reward / not_done:
+ * [size] (contiguous rows); out_index (int64, optional): the ring rows taken. */
+TTL_API int ttl_replay_sample(const float *state, const float *action,
+                              const float *next_state, const float *reward,
+                              const float *not_done, int64_t size, int32_t n_state,
+                              int32_t n_act, int32_t batch, uint32_t key0, uint32_t key1,
+                              float *out_state, float *out_action, float *out_next_state,
+                              float *out_reward, float *out_not_done, int64_t *out_index,
+                              void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,6 +177,10 @@ SYMBOLS = {
                                            C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    'ttl_replay_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
+                                    C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttl_last_error': (C.c_char_p, []),
     'ttl_abi_version': (C.c_uint32, []),
     'ttl_env_desc_size': (C.c_size_t, []),

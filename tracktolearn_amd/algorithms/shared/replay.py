@@ -9,6 +9,8 @@ nothing crosses PCIe.  Ring arithmetic (``ptr``, ``size``, modulo wrap) and
 sampling without replacement (``randperm(size)[:batch]``) follow the
 reference.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -82,7 +84,18 @@ class OffPolicyReplayBuffer(object):
 
     def sample(self, batch_size=4096):
         """min(batch_size, size) transitions without replacement
-        (replay.py:94-143): (s, a, s', r, not_done) on the buffer's device."""
+        (replay.py:94-143): (s, a, s', r, not_done) on the buffer's device.
+
+        On a GPU: one launch of ``ttl_replay_sample`` -- the first ``batch``
+        positions of a keyed pseudo-random permutation of the ring rows,
+        gathered straight into the five tensors; the key comes from torch's
+        CPU generator, so ``torch.manual_seed`` makes a run repeatable.  (The
+        reference permutes all ``size`` rows per call: a 10^6-key sort per
+        training step, 0.28 ms of a 2.4 ms step here.)  ``TTL_REPLAY_RANDPERM=1``
+        and every CPU buffer keep ``randperm`` + ``index_select``."""
+        if self.device.type == 'cuda' and self.size > 0 and \
+                os.environ.get('TTL_REPLAY_RANDPERM', '0') != '1':
+            return self._sample_device(min(self.size, int(batch_size)))
         ind = torch.randperm(self.size, device=self.device)[
             :min(self.size, batch_size)]
         return (self.state.index_select(0, ind),
@@ -90,6 +103,25 @@ class OffPolicyReplayBuffer(object):
                 self.next_state.index_select(0, ind),
                 self.reward.index_select(0, ind).squeeze(-1),
                 self.not_done.index_select(0, ind).squeeze(-1))
+
+    def _sample_device(self, n):
+        import ctypes as C
+
+        from tracktolearn_amd import _lib
+        lib = _lib.load()
+        key = torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int64).tolist()
+        z = dict(dtype=torch.float32, device=self.device)
+        W, A = self.state.shape[1], self.action.shape[1]
+        s, ns = torch.empty((n, W), **z), torch.empty((n, W), **z)
+        a, r, d = torch.empty((n, A), **z), torch.empty(n, **z), torch.empty(n, **z)
+        self.last_indices = torch.empty(n, dtype=torch.int64, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(lib.ttl_replay_sample(
+            self.state.data_ptr(), self.action.data_ptr(), self.next_state.data_ptr(),
+            self.reward.data_ptr(), self.not_done.data_ptr(), self.size, W, A, n,
+            key[0], key[1], s.data_ptr(), a.data_ptr(), ns.data_ptr(), r.data_ptr(),
+            d.data_ptr(), self.last_indices.data_ptr(), stream), 'ttl_replay_sample')
+        return s, a, ns, r, d
 
     def clear_memory(self):
         self.ptr = 0

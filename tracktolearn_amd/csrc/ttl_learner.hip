@@ -667,6 +667,64 @@ __global__ __launch_bounds__(LB) void k_build_learner_inputs(BuildArgs P) {
     if (lane < P.n_act) a_row[P.n_state + lane] = P.a[(int64_t)m * P.ld_a + lane];
 }
 
+// ------------------------------------------------------------------------
+// replay ring: a batch of distinct uniformly drawn transitions in one launch
+// ------------------------------------------------------------------------
+struct SampleArgs {
+    const float *state, *action, *next_state, *reward, *not_done;
+    long long size; int n_state, n_act, batch;
+    unsigned key0, key1;
+    float *o_state, *o_action, *o_next, *o_reward, *o_not_done;
+    long long *o_index;
+    int half_bits;
+};
+
+__device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// position j of a keyed pseudo-random permutation of [0, size): a six-round
+// balanced Feistel network over the next even power of two, cycle-walked back
+// into the range (a bijection of [0, 2^2h) restricted to the orbit of j is a
+// bijection of [0, size): positions 0..batch-1 are distinct indices)
+__device__ __forceinline__ unsigned long long prp_index(unsigned long long j, const SampleArgs &P) {
+    const unsigned mask = (1u << P.half_bits) - 1u;
+    unsigned long long x = j;
+    do {
+        unsigned l = (unsigned)(x >> P.half_bits) & mask, r = (unsigned)x & mask;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const unsigned f = mix32(r * 0x9E3779B1u + ((k & 1) ? P.key1 : P.key0) +
+                                     (unsigned)k * 0x7F4A7C15u);
+            const unsigned t = l ^ (f & mask);
+            l = r;
+            r = t;
+        }
+        x = ((unsigned long long)l << P.half_bits) | r;
+    } while (x >= (unsigned long long)P.size);
+    return x;
+}
+
+__global__ __launch_bounds__(LB) void k_replay_sample(SampleArgs P) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * NW + wv;            // one wave per sampled transition
+    if (j >= P.batch) return;
+    const unsigned long long i = prp_index((unsigned long long)j, P);
+    const float *s = P.state + i * P.n_state, *s2 = P.next_state + i * P.n_state;
+    float *os = P.o_state + (long long)j * P.n_state, *on = P.o_next + (long long)j * P.n_state;
+    for (int c = lane; c < P.n_state; c += 64) {
+        os[c] = s[c];
+        on[c] = s2[c];
+    }
+    if (lane < P.n_act) P.o_action[(long long)j * P.n_act + lane] = P.action[i * P.n_act + lane];
+    if (lane == 0) {
+        P.o_reward[j] = P.reward[i];
+        P.o_not_done[j] = P.not_done[i];
+        if (P.o_index) P.o_index[j] = (long long)i;
+    }
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -897,6 +955,30 @@ int ttl_build_learner_inputs(const float *state, int64_t ld_s, const float *acti
                 w1, ld_w1, w1 ? n_w1_rows : 0, wa, row_blocks};
     k_build_learner_inputs<<<dim3(row_blocks + w_blocks), dim3(LB), 0, S(hip_stream)>>>(P);
     LAUNCH_CHECK("k_build_learner_inputs");
+    return TTL_OK;
+}
+
+int ttl_replay_sample(const float *state, const float *action, const float *next_state,
+                      const float *reward, const float *not_done, int64_t size, int32_t n_state,
+                      int32_t n_act, int32_t batch, uint32_t key0, uint32_t key1,
+                      float *out_state, float *out_action, float *out_next_state,
+                      float *out_reward, float *out_not_done, int64_t *out_index,
+                      void *hip_stream) {
+    if (!state || !action || !next_state || !reward || !not_done || !out_state || !out_action ||
+        !out_next_state || !out_reward || !out_not_done)
+        return fail(TTL_ERR_INVALID, "ttl_replay_sample: null pointer");
+    if (size <= 0 || batch <= 0 || batch > size || n_state <= 0 || n_act <= 0 || n_act > 64 ||
+        size > (1ll << 40))
+        return fail(TTL_ERR_INVALID, "ttl_replay_sample: need 0 < batch <= size (got %d of %lld)",
+                    batch, (long long)size);
+    int bits = 2;
+    while ((1ll << bits) < size) ++bits;
+    if (bits & 1) ++bits;
+    SampleArgs P{state, action, next_state, reward, not_done, (long long)size, n_state, n_act,
+                 batch, key0, key1, out_state, out_action, out_next_state, out_reward,
+                 out_not_done, reinterpret_cast<long long *>(out_index), bits / 2};
+    k_replay_sample<<<dim3((batch + NW - 1) / NW), dim3(LB), 0, S(hip_stream)>>>(P);
+    LAUNCH_CHECK("k_replay_sample");
     return TTL_OK;
 }
 
