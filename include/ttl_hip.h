@@ -392,6 +392,24 @@ TTL_API int ttl_peaks_from_sh(const float *sh, int64_t n_voxels, int32_t n_coef,
                       float min_separation_cos, int32_t max_candidates, float *peaks_out,
                       void *hip_stream);
 
+/* TractOracle-Net forward (TrackToLearn/oracles/transformer_oracle.py:77-92 under the
+ * autocast of oracles/oracle.py:76): scores[i] = sigmoid(head(encoder(embed([CLS; dirs[i]]))[0]))
+ * for n sequences of 127 segment vectors, ONE launch, one wavefront per streamline
+ * (csrc/ttl_oracle_net.hip).  d_model 32, 128 tokens, n_head in {1, 2, 4}, ReLU post-norm
+ * layers, ff_dim a multiple of 32.  The weights come packed by
+ * tracktolearn_amd/oracles/fused_net.py:pack_oracle_net (fp16 MFMA fragments in the k order an
+ * accumulator tile presents, per-row vectors in accumulator row order):
+ *   packed_half  [n_layers][8 + 4 ff_dim / 32][64][8] f16: W_q, W_k, W_v, W_o, W_1 chunks, W_2 chunks
+ *   packed_float [n_layers][288 + ff_dim] f32: b_q, b_k, b_v, b_o, LN1 gain / bias, b_2,
+ *                LN2 gain / bias, b_1 chunks
+ *   embed [2][16][4], cls [3], pos_enc [4][64][16], head [33].
+ * dirs: [n][127][3] f32; scores: [n] f32.  Device pointers. */
+TTL_API int ttl_oracle_net_forward(const float *dirs, int64_t n, const void *packed_half,
+                                   const float *packed_float, const float *embed,
+                                   const float *cls, const float *pos_enc, const float *head,
+                                   int32_t n_layers, int32_t n_head, int32_t ff_dim,
+                                   float *scores, void *hip_stream);
+
 /* Arc-length resampling of a padded batch of streamlines to nb_points points
  * each (the oracle's input, TrackToLearn/oracles/oracle.py:52,70: dipy
  * set_number_of_points).  points: [n] rows of row_pitch floats holding up to

@@ -122,3 +122,106 @@ def test_predict_batching_keeps_the_reference_tail_quirk(tmp_path):
     oracle.drop_tail = False
     assert (oracle.predict(pts) > 0).all()
     OracleSingleton.reset()
+
+
+def _random_oracle(n_head, n_layers, seed, ff=None):
+    """A TransformerOracle with weights of a trained network's size (the
+    default initialisation leaves the attention nearly uniform and the scores
+    within 1e-2 of each other: too easy a target)."""
+    from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
+    torch.manual_seed(seed)
+    model = TransformerOracle(381, 1, n_head, n_layers, 1e-4)
+    if ff is not None:
+        for layer in model.bert.layers:
+            layer.linear1 = torch.nn.Linear(32, ff)
+            layer.linear2 = torch.nn.Linear(ff, 32)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if 'in_proj_weight' in name:
+                p.mul_(3.0)
+            elif name.endswith('bias') or 'norm' in name:
+                p.add_(0.2 * torch.randn_like(p))
+        model.head.weight.mul_(6.0)
+    return model.eval()
+
+
+def test_oracle_net_packing_layout():
+    """Host-side packing of the fused network (oracles/fused_net.py): fragment
+    element j of lane (r, h) of k-step s is w[r][16 s + 8 (j >> 2) + 4 h + (j & 3)],
+    per-row vectors follow the accumulator's row order."""
+    from tracktolearn_amd.oracles.fused_net import FusedOracleNet, pack32, pack_oracle_net, rowpack
+    w = torch.arange(1024, dtype=torch.float32).view(32, 32)
+    f = pack32(w)
+    assert f.shape == (2, 64, 8)
+    for s, lane, j in ((0, 0, 0), (1, 37, 5), (0, 63, 7), (1, 31, 3)):
+        r, h = lane & 31, lane >> 5
+        assert float(f[s, lane, j]) == float(w[r, 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)])
+    # every k index appears once per (lane row) over the two steps and two halves
+    assert sorted(f[:, [5, 37]].reshape(-1).tolist()) == w[5].tolist()
+    v = torch.arange(32.0)
+    rp = rowpack(v)
+    assert rp.shape == (2, 16) and sorted(rp.reshape(-1).tolist()) == v.tolist()
+    assert float(rp[1, 6]) == 8 * (6 >> 2) + 4 + (6 & 3)
+    model = _random_oracle(4, 2, 0)
+    assert FusedOracleNet.supports(model)
+    p = pack_oracle_net(model, 'cpu')
+    assert p['wh'].shape == (2, (8 + 4 * 64) * 512) and p['wf'].shape == (2, 288 + 2048)
+    assert p['embed'].shape == (2, 16, 4) and p['pe'].shape == (4, 64, 16) and p['head'].shape == (33,)
+    # an architecture the kernel does not implement keeps the PyTorch module
+    from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
+    assert not FusedOracleNet.supports(TransformerOracle(381, 1, 8, 2, 1e-4))
+    assert not FusedOracleNet.supports(TransformerOracle(300, 1, 4, 2, 1e-4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_head,n_layers,ff', [(4, 4, None), (4, 1, None), (2, 2, 96), (1, 3, 64)])
+def test_fused_oracle_net_matches_the_module(n_head, n_layers, ff):
+    """`ttl_oracle_net_forward` (one wavefront per streamline, fp16 MFMA,
+    everything in registers) against the PyTorch module: under
+    `torch.autocast` -- the arithmetic it restates -- and in float32.  The
+    fused scores may be no further from float32 than 3 x what autocast itself
+    is, and within 4e-3 of autocast's."""
+    from tracktolearn_amd.oracles.fused_net import FusedOracleNet
+    model = _random_oracle(n_head, n_layers, 7 + n_head, ff).cuda()
+    net = FusedOracleNet(model)
+    g = torch.Generator().manual_seed(11)
+    for n in (1, 3, 4, 257, 4096):
+        # segment vectors of resampled streamlines: smooth random walks, ~0.3 long
+        steps = torch.randn(n, 127, 3, generator=g) * 0.05
+        base = torch.randn(n, 1, 3, generator=g) * 0.3
+        dirs = (base + torch.cumsum(steps, 1) * 0.3).cuda()
+        with torch.no_grad():
+            y32 = model(dirs).float()
+            with torch.autocast('cuda'):
+                y16 = model(dirs).float()
+        got = net(dirs)
+        assert got.shape == (n,) and bool(((got > 0) & (got < 1)).all())
+        e_auto = float((y16 - y32).abs().max())
+        e_fused = float((got - y32).abs().max())
+        d = float((got - y16).abs().max())
+        print(f'heads {n_head} layers {n_layers} n {n}: scores {float(y32.min()):.3f}..'
+              f'{float(y32.max()):.3f}, autocast err {e_auto:.2e}, fused err {e_fused:.2e}, '
+              f'fused vs autocast {d:.2e}')
+        assert float(y32.max() - y32.min()) > 0.05 or n < 4      # the scores do spread
+        assert e_fused <= 3 * e_auto + 2e-3 and d <= 4e-3
+    # rows are independent: a row's score does not depend on its batch
+    one = net(dirs[100:101])
+    assert torch.equal(one, got[100:101])
+
+
+@pytest.mark.gpu
+def test_reference_transformer_vector_through_the_fused_net():
+    """The reference's own `TransformerOracle.forward` vector
+    (tests/golden/oracle_transformer.npz) through the fused kernel: within
+    the 5e-3 the autocast module is held to."""
+    from tracktolearn_amd.oracles.fused_net import FusedOracleNet
+    from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
+    z = load_trace('oracle_transformer')
+    model = TransformerOracle(int(z['input_size']), 1, int(z['n_head']), int(z['n_layers']), 1e-4)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k].astype(np.float32))
+                           for k in z.files if k.startswith('sd/')})
+    model = model.cuda().eval()
+    if not FusedOracleNet.supports(model):
+        pytest.skip('golden vector of another architecture')
+    y = FusedOracleNet(model)(torch.from_numpy(z['x']).cuda()).cpu().numpy()
+    assert np.abs(y - z['y']).max() <= 5e-3

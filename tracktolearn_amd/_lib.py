@@ -143,6 +143,10 @@ SYMBOLS = {
     'ttl_resample_streamlines': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_void_p]),
+    'ttl_oracle_net_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                         C.c_void_p]),
     'ttl_pack_streamlines': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_void_p, C.c_void_p]),
     # ---- include/ttl_learner.h

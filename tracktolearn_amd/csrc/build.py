@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 SOURCES = [os.path.join(HERE, f) for f in
-           ('ttl_hip.hip', 'ttl_state.hip', 'ttl_peaks.hip', 'ttl_resample.hip', 'ttl_order.hip', 'ttl_learner.hip')]
+           ('ttl_hip.hip', 'ttl_state.hip', 'ttl_peaks.hip', 'ttl_resample.hip', 'ttl_order.hip', 'ttl_learner.hip',
+            'ttl_oracle_net.hip')]
 HEADERS = [os.path.join(ROOT, 'include', 'ttl_hip.h'),
            os.path.join(ROOT, 'include', 'ttl_learner.h'),
            os.path.join(HERE, 'ttl_internal.h')]

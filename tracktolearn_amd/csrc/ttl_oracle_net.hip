@@ -1,0 +1,364 @@
+// ttl_oracle_net.hip -- TractOracle-Net (TrackToLearn/oracles/transformer_oracle.py:38-118)
+// as ONE kernel: the streamline-scoring transformer of the oracle reward / oracle stopping
+// criterion (oracle_reward.py:70-93, stopping_criteria.py:85-154, oracles/oracle.py:39-89).
+//
+// The network is tiny and oddly shaped for a GEMM library -- d_model 32, 128 tokens, 4 heads of
+// 8, a 2 048-wide feed-forward block, 4 post-norm layers: 147 MFLOP per streamline, almost all
+// of it two GEMMs with K or N = 32 -- and PyTorch's fp16-autocast path (what the reference runs)
+// reaches ~45 TFLOP/s on it, 2 % of the MI355X's dense fp16 MFMA rate.  Here one wavefront owns
+// one streamline and keeps the whole sequence in registers, transposed: h^T [32 features x 128
+// tokens] as four 32x32 accumulator tiles (column = token = lane & 31, rows = features in the 16
+// registers of the two lane halves).  Every product of the layer is arranged so that it sums
+// over the ROW index of an accumulator tile, which `v_mfma_f32_32x32x16_f16` can take as its A or
+// B operand straight from the registers (cdna_hip_programming.md, "an accumulator tile as the
+// next MFMA's operand"): no LDS, no lane movement except one half-swap per softmax / LayerNorm
+// reduction.  The k order inside such a fragment is permuted (element j of lane half h is row
+// 16 s + 8 (j >> 2) + 4 h + (j & 3)), so the weights are packed on the host once per model in
+// exactly that order (oracles/fused_net.py:pack_oracle_net).
+//
+//   Q^T, K^T = W_q,k . h^T            A = packed weights, B = h^T fragments
+//   V        = h . W_v^T              A = h^T fragments (as h), B = packed weights
+//   S_h^T    = K . (Q^T masked to head h)         A = K^T fragments (as K), B = Q^T fragments
+//   O^T     += (V^T masked to head h) . P_h^T      A = V fragments (as V^T), B = P^T fragments
+//   o^T      = W_o . O^T,  f^T = W_2 . relu(W_1 . h^T)   (the 2 048-wide intermediate lives in
+//                                      16 registers per 32-unit chunk and is never stored)
+//
+// The last layer only needs token 0 (the CLS position feeds the head): its attention output,
+// feed-forward block and LayerNorms run on the first token tile only.
+//
+// Arithmetic as under torch.autocast(fp16): fp16 operands, fp32 accumulation, Linear outputs
+// rounded to fp16, softmax and LayerNorm in fp32.
+#include "ttl_internal.h"
+#include "ttl_learner.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+constexpr int NT = 4;            // token tiles of 32 (128 tokens)
+constexpr float LN_EPS = 1e-5f;
+
+struct NetArgs {
+    const float *dirs;           // [n][127][3]
+    long long n;
+    const _Float16 *wh;          // packed half weights, all layers
+    const float *wf;             // packed float vectors, all layers
+    const float *embed;          // [2][16][4]: w0, w1, w2, b of feature fperm(a, hi)
+    const float *cls;            // [3]
+    const float *pe;             // [4][64][16]
+    const float *head;           // [2][16] weights + [1] bias
+    int n_layers, ff_chunks;
+    long long wh_stride, wf_stride;      // per layer, in h8 fragments-of-lane / floats
+    float *out;
+};
+
+__device__ __forceinline__ float swap_halves(float v) { return __shfl_xor(v, 32); }
+
+__device__ __forceinline__ void to_frags(const f16x &x, h8 (&f)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[s][j] = (_Float16)x[8 * s + j];
+}
+
+__device__ __forceinline__ f16x mfma(const h8 &a, const h8 &b, const f16x &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f16x zero16() {
+    f16x z;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) z[a] = 0.f;
+    return z;
+}
+
+// x[a] += v[a] for a per-row vector packed [2 halves][16]
+__device__ __forceinline__ void add_rows(f16x &x, const float *p, int hi) {
+    const float *q = p + hi * 16;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) x[a] += q[a];
+}
+
+// Linear outputs are fp16 under autocast
+__device__ __forceinline__ void round_fp16(f16x &x) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) x[a] = (float)(_Float16)x[a];
+}
+
+__device__ __forceinline__ void layer_norm(f16x &x, const float *g, const float *b, int hi) {
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) sum += x[a];
+    sum += swap_halves(sum);
+    const float mean = sum * (1.f / 32.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const float d = x[a] - mean;
+        sq += d * d;
+    }
+    sq += swap_halves(sq);
+    const float rstd = 1.f / sqrtf(sq * (1.f / 32.f) + LN_EPS);
+    const float *gg = g + hi * 16, *bb = b + hi * 16;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) x[a] = (x[a] - mean) * rstd * gg[a] + bb[a];
+}
+
+template <int NHEAD>
+__global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
+    constexpr int DH = 32 / NHEAD;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wv;        // one wave per streamline
+    if (row >= P.n) return;
+    const int n = lane & 31, hi = lane >> 5;
+    const float *dirs = P.dirs + row * (127 * 3);
+
+    // ---- embedding: relu(W_e x + b_e) * sqrt(32) + positional encoding
+    f16x hT[NT];
+    {
+        const float *E = P.embed + hi * 64;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int t = 32 * nt + n;
+            float x0, x1, x2;
+            if (t == 0) {
+                x0 = P.cls[0]; x1 = P.cls[1]; x2 = P.cls[2];
+            } else {
+                const float *d = dirs + (t - 1) * 3;
+                x0 = d[0]; x1 = d[1]; x2 = d[2];
+            }
+            // autocast: inputs and weights of the Linear in fp16, fp32 accumulation,
+            // fp16 result; ReLU and the sqrt(32) scale in fp16; the table add in fp32
+            x0 = (float)(_Float16)x0; x1 = (float)(_Float16)x1; x2 = (float)(_Float16)x2;
+            const float *pe = P.pe + ((long long)nt * 64 + lane) * 16;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                float e = E[4 * a + 0] * x0 + E[4 * a + 1] * x1 + E[4 * a + 2] * x2 + E[4 * a + 3];
+                e = (float)(_Float16)e;
+                e = e > 0.f ? e : 0.f;
+                e = (float)(_Float16)(e * (float)(_Float16)5.656854249492381f);
+                hT[nt][a] = e + pe[a];
+            }
+        }
+    }
+
+    for (int layer = 0; layer < P.n_layers; ++layer) {
+        const bool last = layer == P.n_layers - 1;
+        const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
+        const float *WF = P.wf + (long long)layer * P.wf_stride;
+        const h8 *Wqk = WH;                     // [2 mt][2 s][64]
+        const h8 *Wv = WH + 4 * 64;             // [2 s][64]
+        const h8 *Wo = WH + 6 * 64;             // [2 s][64]
+        const h8 *W1 = WH + 8 * 64;             // [C][2 s][64]
+        const h8 *W2 = W1 + (long long)P.ff_chunks * 2 * 64;
+        const float *bqk = WF;                  // [2][2][16]
+        const float *bv = WF + 64;              // [32]
+        const float *bo = WF + 96;              // [2][16]
+        const float *g1 = WF + 128, *be1 = WF + 160;
+        const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
+        const float *b1 = WF + 288;             // [C][2][16]
+
+        // ---- h^T as fp16 operand fragments (k = feature, permuted order)
+        h8 hB[NT][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) to_frags(hT[nt], hB[nt]);
+
+        // ---- Q^T, K^T [features x tokens] and V [tokens x features]
+        h8 QB[NT][2], KA[NT][2], VA[NT][2];
+        {
+            const h8 wq0 = Wqk[0 * 64 + lane], wq1 = Wqk[1 * 64 + lane];
+            const h8 wk0 = Wqk[2 * 64 + lane], wk1 = Wqk[3 * 64 + lane];
+            const h8 wv0 = Wv[0 * 64 + lane], wv1 = Wv[1 * 64 + lane];
+            const float bvc = bv[n];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f16x q = mfma(wq1, hB[nt][1], mfma(wq0, hB[nt][0], zero16()));
+                add_rows(q, bqk, hi);
+                to_frags(q, QB[nt]);
+                f16x k = mfma(wk1, hB[nt][1], mfma(wk0, hB[nt][0], zero16()));
+                add_rows(k, bqk + 32, hi);
+                to_frags(k, KA[nt]);
+                // V tile: rows = tokens of this tile, column (lane) = feature n
+                f16x v = mfma(hB[nt][1], wv1, mfma(hB[nt][0], wv0, zero16()));
+#pragma unroll
+                for (int a = 0; a < 16; ++a) v[a] += bvc;
+                to_frags(v, VA[nt]);
+            }
+        }
+
+        // ---- attention, one query tile at a time; out-projection, residual, LayerNorm 1
+        const float scale = 1.4426950408889634f / sqrtf((float)DH);     // log2(e) / sqrt(dh)
+        const int nq = last ? 1 : NT;           // the last layer only needs token 0
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nq) break;
+            f16x OT = zero16();
+#pragma unroll
+            for (int h = 0; h < NHEAD; ++h) {
+                // scores S^T [keys x queries] of head h
+                f16x S[NT];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) {
+                    if constexpr (NHEAD == 1) {
+                        S[mt] = mfma(KA[mt][1], QB[nt][1], mfma(KA[mt][0], QB[nt][0], zero16()));
+                    } else if constexpr (NHEAD == 2) {
+                        S[mt] = mfma(KA[mt][h], QB[nt][h], zero16());
+                    } else {
+                        // head h = features 8h..8h+7 = elements 4 (h & 1) .. +3 of k-step h >> 1
+                        h8 qm = QB[nt][h >> 1];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if ((j >> 2) != (h & 1)) qm[j] = (_Float16)0.f;
+                        S[mt] = mfma(KA[mt][h >> 1], qm, zero16());
+                    }
+                }
+                // softmax over the keys of each query (= over rows, per lane column)
+                float m = S[0][0];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) m = fmaxf(m, S[mt][a]);
+                m = fmaxf(m, swap_halves(m));
+                float l = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) {
+                        const float p = __builtin_amdgcn_exp2f((S[mt][a] - m) * scale);
+                        S[mt][a] = p;
+                        l += p;
+                    }
+                l += swap_halves(l);
+                const float inv = 1.f / l;
+                // O^T += V^T (rows of head h only) . P^T
+                const bool mine = (n / DH) == h;        // this lane's V column belongs to head h
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) {
+                    h8 PB[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) PB[s][j] = (_Float16)(S[mt][8 * s + j] * inv);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        h8 va = VA[mt][s];
+                        if constexpr (NHEAD > 1) {
+                            if (!mine) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) va[j] = (_Float16)0.f;
+                            }
+                        }
+                        OT = mfma(va, PB[s], OT);
+                    }
+                }
+            }
+            // out-projection on the fp16 attention output, residual, LayerNorm 1
+            h8 OB[2];
+            to_frags(OT, OB);
+            f16x o = mfma(Wo[64 + lane], OB[1], mfma(Wo[lane], OB[0], zero16()));
+            add_rows(o, bo, hi);
+            round_fp16(o);
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hT[nt][a] += o[a];
+            layer_norm(hT[nt], g1, be1, hi);
+        }
+
+        // ---- feed-forward: f^T = W_2 . relu(W_1 . h^T + b_1) + b_2, 32 hidden units at a time
+        h8 fB[NT][2];
+        f16x D2[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nq) break;
+            to_frags(hT[nt], fB[nt]);
+            D2[nt] = zero16();
+        }
+        h8 w1a = W1[lane], w1b = W1[64 + lane], w2a = W2[lane], w2b = W2[64 + lane];
+        for (int c = 0; c < P.ff_chunks; ++c) {
+            // prefetch the next chunk's weights while this one is multiplied
+            const int cn = c + 1 < P.ff_chunks ? c + 1 : c;
+            const h8 n1a = W1[(long long)cn * 128 + lane], n1b = W1[(long long)cn * 128 + 64 + lane];
+            const h8 n2a = W2[(long long)cn * 128 + lane], n2b = W2[(long long)cn * 128 + 64 + lane];
+            float bias[16];
+            {
+                const float *q = b1 + (long long)c * 32 + hi * 16;
+#pragma unroll
+                for (int a = 0; a < 16; ++a) bias[a] = q[a];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt >= nq) break;
+                f16x d1 = mfma(w1b, fB[nt][1], mfma(w1a, fB[nt][0], zero16()));
+                h8 F[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // Linear output in fp16, then ReLU
+                        const _Float16 u = (_Float16)(d1[8 * s + j] + bias[8 * s + j]);
+                        F[s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
+                    }
+                D2[nt] = mfma(w2b, F[1], mfma(w2a, F[0], D2[nt]));
+            }
+            w1a = n1a; w1b = n1b; w2a = n2a; w2b = n2b;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt >= nq) break;
+            add_rows(D2[nt], b2, hi);
+            round_fp16(D2[nt]);
+#pragma unroll
+            for (int a = 0; a < 16; ++a) hT[nt][a] += D2[nt][a];
+            layer_norm(hT[nt], g2, be2, hi);
+        }
+    }
+
+    // ---- head on the CLS position (token 0 = tile 0, lane column 0 of both halves)
+    float dot = 0.f;
+    {
+        const float *w = P.head + hi * 16;
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            dot += (float)(_Float16)hT[0][a] * (float)(_Float16)w[a];
+    }
+    dot += swap_halves(dot);
+    if (lane == 0) {
+        float y = (float)(_Float16)(dot + (float)(_Float16)P.head[32]);
+        y = 1.f / (1.f + expf(-y));
+        P.out[row] = (float)(_Float16)y;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ttl_oracle_net_forward(const float *dirs, int64_t n, const void *packed_half,
+                           const float *packed_float, const float *embed, const float *cls,
+                           const float *pos_enc, const float *head, int32_t n_layers,
+                           int32_t n_head, int32_t ff_dim, float *scores, void *hip_stream) {
+    if (!dirs || !packed_half || !packed_float || !embed || !cls || !pos_enc || !head || !scores)
+        return fail(TTL_ERR_INVALID, "ttl_oracle_net_forward: null pointer");
+    if (n <= 0 || n_layers <= 0 || ff_dim <= 0 || ff_dim % 32)
+        return fail(TTL_ERR_INVALID, "ttl_oracle_net_forward: bad shape (n %lld, layers %d, ff %d)",
+                    (long long)n, n_layers, ff_dim);
+    if (n_head != 1 && n_head != 2 && n_head != 4)
+        return fail(TTL_ERR_UNSUPPORTED, "ttl_oracle_net_forward: 1, 2 or 4 heads (got %d)", n_head);
+    if (((uintptr_t)packed_half & 15u) || ((uintptr_t)packed_float & 15u))
+        return fail(TTL_ERR_INVALID, "ttl_oracle_net_forward: packed weights must be 16-byte aligned");
+    const int chunks = ff_dim / 32;
+    NetArgs P{dirs, (long long)n, reinterpret_cast<const _Float16 *>(packed_half), packed_float,
+              embed, cls, pos_enc, head, n_layers, chunks,
+              (long long)(8 + 4 * chunks) * 64, (long long)288 + 32 * chunks, scores};
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (n_head == 1) k_oracle_net<1><<<grid, block, 0, s>>>(P);
+    else if (n_head == 2) k_oracle_net<2><<<grid, block, 0, s>>>(P);
+    else k_oracle_net<4><<<grid, block, 0, s>>>(P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(TTL_ERR_HIP, "k_oracle_net: %s", hipGetErrorString(e));
+    return TTL_OK;
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@ the final *partial* batch is never evaluated and its scores stay 0
 (oracle.py:62-84); ``drop_tail=False`` scores everything.
 """
 import contextlib
+import os
 
 import torch
 
@@ -85,6 +86,14 @@ class OracleSingleton:
         #: streamline), so the scores of the real rows do not depend on the padding.
         self.pad_rows = 512 if self.device.type == 'cuda' else 0
         self._pad_buf = None
+        #: the network as one hand-written kernel (oracles/fused_net.py) when it has
+        #: the reference's architecture; ``TTL_ORACLE_FUSED=0`` keeps the PyTorch
+        #: module under autocast (A/B runs; other architectures always do)
+        self.net = None
+        if self.device.type == 'cuda' and os.environ.get('TTL_ORACLE_FUSED', '1') != '0':
+            from tracktolearn_amd.oracles.fused_net import FusedOracleNet
+            if FusedOracleNet.supports(self.model):
+                self.net = FusedOracleNet(self.model, self.device)
         # the resampler is the HIP kernel; CPU-only tests of the batching
         # logic inject the PyTorch restatement from tests/
         self._resample = resample if resample is not None else resample_streamlines
@@ -119,6 +128,9 @@ class OracleSingleton:
         for lo, hi in spans:
             data = self._resample(points[lo:hi], lengths[lo:hi], 128)
             dirs = (data[:, 1:] - data[:, :-1]).float()
+            if self.net is not None:
+                result[lo:hi] = self.net(dirs)
+                continue
             rows = hi - lo
             padded = -(-rows // self.pad_rows) * self.pad_rows if self.pad_rows else rows
             if padded != rows:
