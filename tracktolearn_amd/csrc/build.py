@@ -30,6 +30,10 @@ FLAGS = [
     # only the TTL_API entry points of include/ttl_hip.h leave the library
     '-fvisibility=hidden', '-fvisibility-inlines-hidden',
     '-Wall', '-Wno-unused-function',
+    # MFMA results the VALU consumes next (ttl_oracle_net.hip: every accumulator tile is
+    # converted to fp16 operand fragments) go to architectural VGPRs, not to AGPRs that
+    # would have to be copied out one v_accvgpr_read at a time
+    '-mllvm', '-amdgpu-mfma-vgpr-form=1',
 ]
 
 

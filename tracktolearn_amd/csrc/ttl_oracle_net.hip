@@ -105,9 +105,199 @@ __device__ __forceinline__ void layer_norm(f16x &x, const float *g, const float 
     for (int a = 0; a < 16; ++a) x[a] = (x[a] - mean) * rstd * gg[a] + bb[a];
 }
 
+// One encoder layer on the wave's streamline.  NQ = 4: all four token tiles; NQ = 1 (the
+// last layer): keys and values of all tokens, but queries, out-projection, feed-forward and
+// LayerNorms of the first tile only (the head reads token 0).  A compile-time NQ keeps the
+// tile loops free of branches, so the scheduler interleaves the tiles' MFMA chains.
+template <int NHEAD, int NQ>
+__device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, int layer,
+                                              int lane, int n, int hi) {
+    constexpr int DH = 32 / NHEAD;
+    const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
+    const float *WF = P.wf + (long long)layer * P.wf_stride;
+    const h8 *Wqk = WH;                     // [2 mt][2 s][64]
+    const h8 *Wv = WH + 4 * 64;             // [2 s][64]
+    const h8 *Wo = WH + 6 * 64;             // [2 s][64]
+    const h8 *W1 = WH + 8 * 64;             // [C][2 s][64]
+    const h8 *W2 = W1 + (long long)P.ff_chunks * 2 * 64;
+    const float *bqk = WF;                  // [2][2][16]
+    const float *bv = WF + 64;              // [32]
+    const float *bo = WF + 96;              // [2][16]
+    const float *g1 = WF + 128, *be1 = WF + 160;
+    const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
+    const float *b1 = WF + 288;             // [C][2][16]
+
+    // ---- Q^T, K^T [features x tokens] and V [tokens x features]
+    h8 QB[NQ][2], KA[NT][2], VA[NT][2];
+    {
+        const h8 wq0 = Wqk[0 * 64 + lane], wq1 = Wqk[1 * 64 + lane];
+        const h8 wk0 = Wqk[2 * 64 + lane], wk1 = Wqk[3 * 64 + lane];
+        const h8 wv0 = Wv[0 * 64 + lane], wv1 = Wv[1 * 64 + lane];
+        const float bvc = bv[n];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // h^T as fp16 operand fragments (k = feature, permuted order)
+            h8 hB[2];
+            to_frags(hT[nt], hB);
+            if (nt < NQ) {
+                f16x q = mfma(wq1, hB[1], mfma(wq0, hB[0], zero16()));
+                add_rows(q, bqk, hi);
+                to_frags(q, QB[nt < NQ ? nt : 0]);
+            }
+            f16x k = mfma(wk1, hB[1], mfma(wk0, hB[0], zero16()));
+            add_rows(k, bqk + 32, hi);
+            to_frags(k, KA[nt]);
+            // V tile: rows = tokens of this tile, column (lane) = feature n
+            f16x v = mfma(hB[1], wv1, mfma(hB[0], wv0, zero16()));
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] += bvc;
+            to_frags(v, VA[nt]);
+        }
+    }
+
+    // ---- attention, one query tile at a time; out-projection, residual, LayerNorm 1
+    const float scale = 1.4426950408889634f / sqrtf((float)DH);     // log2(e) / sqrt(dh)
+#pragma unroll
+    for (int nt = 0; nt < NQ; ++nt) {
+        f16x OT = zero16();
+#pragma unroll
+        for (int h = 0; h < NHEAD; ++h) {
+            // scores S^T [keys x queries] of head h
+            f16x S[NT];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                if constexpr (NHEAD == 1) {
+                    S[mt] = mfma(KA[mt][1], QB[nt][1], mfma(KA[mt][0], QB[nt][0], zero16()));
+                } else if constexpr (NHEAD == 2) {
+                    S[mt] = mfma(KA[mt][h], QB[nt][h], zero16());
+                } else {
+                    // head h = features 8h..8h+7 = elements 4 (h & 1) .. +3 of k-step h >> 1
+                    h8 qm = QB[nt][h >> 1];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if ((j >> 2) != (h & 1)) qm[j] = (_Float16)0.f;
+                    S[mt] = mfma(KA[mt][h >> 1], qm, zero16());
+                }
+            }
+            // softmax over the keys of each query (= over rows, per lane column)
+            float m = S[0][0];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int a = 0; a < 16; ++a) m = fmaxf(m, S[mt][a]);
+            m = fmaxf(m, swap_halves(m));
+            float l = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    const float p = __builtin_amdgcn_exp2f((S[mt][a] - m) * scale);
+                    S[mt][a] = p;
+                    l += p;
+                }
+            l += swap_halves(l);
+            const float inv = 1.f / l;
+            // O^T += V^T (rows of head h only) . P^T
+            const bool mine = (n / DH) == h;        // this lane's V column belongs to head h
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                h8 PB[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) PB[s][j] = (_Float16)(S[mt][8 * s + j] * inv);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    h8 va = VA[mt][s];
+                    if constexpr (NHEAD > 1) {
+                        if (!mine) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) va[j] = (_Float16)0.f;
+                        }
+                    }
+                    OT = mfma(va, PB[s], OT);
+                }
+            }
+        }
+        // out-projection on the fp16 attention output, residual, LayerNorm 1
+        h8 OB[2];
+        to_frags(OT, OB);
+        f16x o = mfma(Wo[64 + lane], OB[1], mfma(Wo[lane], OB[0], zero16()));
+        add_rows(o, bo, hi);
+        round_fp16(o);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) hT[nt][a] += o[a];
+        layer_norm(hT[nt], g1, be1, hi);
+    }
+
+    // ---- feed-forward: f^T = W_2 . relu(W_1 . h^T + b_1) + b_2, 32 hidden units at a time
+    h8 fB[NQ][2];
+    f16x D2[NQ];
+#pragma unroll
+    for (int nt = 0; nt < NQ; ++nt) {
+        to_frags(hT[nt], fB[nt]);
+        D2[nt] = zero16();
+    }
+    h8 w1a = W1[lane], w1b = W1[64 + lane], w2a = W2[lane], w2b = W2[64 + lane];
+    float bias[16];
+    {
+        const float *q = b1 + hi * 16;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) bias[a] = q[a];
+    }
+    for (int c = 0; c < P.ff_chunks; ++c) {
+        // prefetch the next chunk's weights and bias while this one is multiplied
+        const int cn = c + 1 < P.ff_chunks ? c + 1 : c;
+        const h8 n1a = W1[(long long)cn * 128 + lane], n1b = W1[(long long)cn * 128 + 64 + lane];
+        const h8 n2a = W2[(long long)cn * 128 + lane], n2b = W2[(long long)cn * 128 + 64 + lane];
+        float nbias[16];
+        {
+            const float *q = b1 + (long long)cn * 32 + hi * 16;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) nbias[a] = q[a];
+        }
+        // the tiles' chains side by side: GEMM 1 of every tile (the bias rides in as the
+        // accumulator's initial value), the fp16 round + ReLU of every tile, GEMM 2
+        f16x d1[NQ];
+#pragma unroll
+        for (int nt = 0; nt < NQ; ++nt) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) d1[nt][a] = bias[a];
+            d1[nt] = mfma(w1a, fB[nt][0], d1[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NQ; ++nt) d1[nt] = mfma(w1b, fB[nt][1], d1[nt]);
+        h8 F[NQ][2];
+#pragma unroll
+        for (int nt = 0; nt < NQ; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // Linear output in fp16, then ReLU
+                    const _Float16 u = (_Float16)d1[nt][8 * s + j];
+                    F[nt][s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
+                }
+#pragma unroll
+        for (int nt = 0; nt < NQ; ++nt) D2[nt] = mfma(w2a, F[nt][0], D2[nt]);
+#pragma unroll
+        for (int nt = 0; nt < NQ; ++nt) D2[nt] = mfma(w2b, F[nt][1], D2[nt]);
+        w1a = n1a; w1b = n1b; w2a = n2a; w2b = n2b;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) bias[a] = nbias[a];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NQ; ++nt) {
+        add_rows(D2[nt], b2, hi);
+        round_fp16(D2[nt]);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) hT[nt][a] += D2[nt][a];
+        layer_norm(hT[nt], g2, be2, hi);
+    }
+}
+
 template <int NHEAD>
 __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
-    constexpr int DH = 32 / NHEAD;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wv;        // one wave per streamline
     if (row >= P.n) return;
@@ -143,175 +333,9 @@ __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
         }
     }
 
-    for (int layer = 0; layer < P.n_layers; ++layer) {
-        const bool last = layer == P.n_layers - 1;
-        const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
-        const float *WF = P.wf + (long long)layer * P.wf_stride;
-        const h8 *Wqk = WH;                     // [2 mt][2 s][64]
-        const h8 *Wv = WH + 4 * 64;             // [2 s][64]
-        const h8 *Wo = WH + 6 * 64;             // [2 s][64]
-        const h8 *W1 = WH + 8 * 64;             // [C][2 s][64]
-        const h8 *W2 = W1 + (long long)P.ff_chunks * 2 * 64;
-        const float *bqk = WF;                  // [2][2][16]
-        const float *bv = WF + 64;              // [32]
-        const float *bo = WF + 96;              // [2][16]
-        const float *g1 = WF + 128, *be1 = WF + 160;
-        const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
-        const float *b1 = WF + 288;             // [C][2][16]
-
-        // ---- h^T as fp16 operand fragments (k = feature, permuted order)
-        h8 hB[NT][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) to_frags(hT[nt], hB[nt]);
-
-        // ---- Q^T, K^T [features x tokens] and V [tokens x features]
-        h8 QB[NT][2], KA[NT][2], VA[NT][2];
-        {
-            const h8 wq0 = Wqk[0 * 64 + lane], wq1 = Wqk[1 * 64 + lane];
-            const h8 wk0 = Wqk[2 * 64 + lane], wk1 = Wqk[3 * 64 + lane];
-            const h8 wv0 = Wv[0 * 64 + lane], wv1 = Wv[1 * 64 + lane];
-            const float bvc = bv[n];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                f16x q = mfma(wq1, hB[nt][1], mfma(wq0, hB[nt][0], zero16()));
-                add_rows(q, bqk, hi);
-                to_frags(q, QB[nt]);
-                f16x k = mfma(wk1, hB[nt][1], mfma(wk0, hB[nt][0], zero16()));
-                add_rows(k, bqk + 32, hi);
-                to_frags(k, KA[nt]);
-                // V tile: rows = tokens of this tile, column (lane) = feature n
-                f16x v = mfma(hB[nt][1], wv1, mfma(hB[nt][0], wv0, zero16()));
-#pragma unroll
-                for (int a = 0; a < 16; ++a) v[a] += bvc;
-                to_frags(v, VA[nt]);
-            }
-        }
-
-        // ---- attention, one query tile at a time; out-projection, residual, LayerNorm 1
-        const float scale = 1.4426950408889634f / sqrtf((float)DH);     // log2(e) / sqrt(dh)
-        const int nq = last ? 1 : NT;           // the last layer only needs token 0
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (nt >= nq) break;
-            f16x OT = zero16();
-#pragma unroll
-            for (int h = 0; h < NHEAD; ++h) {
-                // scores S^T [keys x queries] of head h
-                f16x S[NT];
-#pragma unroll
-                for (int mt = 0; mt < NT; ++mt) {
-                    if constexpr (NHEAD == 1) {
-                        S[mt] = mfma(KA[mt][1], QB[nt][1], mfma(KA[mt][0], QB[nt][0], zero16()));
-                    } else if constexpr (NHEAD == 2) {
-                        S[mt] = mfma(KA[mt][h], QB[nt][h], zero16());
-                    } else {
-                        // head h = features 8h..8h+7 = elements 4 (h & 1) .. +3 of k-step h >> 1
-                        h8 qm = QB[nt][h >> 1];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if ((j >> 2) != (h & 1)) qm[j] = (_Float16)0.f;
-                        S[mt] = mfma(KA[mt][h >> 1], qm, zero16());
-                    }
-                }
-                // softmax over the keys of each query (= over rows, per lane column)
-                float m = S[0][0];
-#pragma unroll
-                for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                    for (int a = 0; a < 16; ++a) m = fmaxf(m, S[mt][a]);
-                m = fmaxf(m, swap_halves(m));
-                float l = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                    for (int a = 0; a < 16; ++a) {
-                        const float p = __builtin_amdgcn_exp2f((S[mt][a] - m) * scale);
-                        S[mt][a] = p;
-                        l += p;
-                    }
-                l += swap_halves(l);
-                const float inv = 1.f / l;
-                // O^T += V^T (rows of head h only) . P^T
-                const bool mine = (n / DH) == h;        // this lane's V column belongs to head h
-#pragma unroll
-                for (int mt = 0; mt < NT; ++mt) {
-                    h8 PB[2];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) PB[s][j] = (_Float16)(S[mt][8 * s + j] * inv);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        h8 va = VA[mt][s];
-                        if constexpr (NHEAD > 1) {
-                            if (!mine) {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) va[j] = (_Float16)0.f;
-                            }
-                        }
-                        OT = mfma(va, PB[s], OT);
-                    }
-                }
-            }
-            // out-projection on the fp16 attention output, residual, LayerNorm 1
-            h8 OB[2];
-            to_frags(OT, OB);
-            f16x o = mfma(Wo[64 + lane], OB[1], mfma(Wo[lane], OB[0], zero16()));
-            add_rows(o, bo, hi);
-            round_fp16(o);
-#pragma unroll
-            for (int a = 0; a < 16; ++a) hT[nt][a] += o[a];
-            layer_norm(hT[nt], g1, be1, hi);
-        }
-
-        // ---- feed-forward: f^T = W_2 . relu(W_1 . h^T + b_1) + b_2, 32 hidden units at a time
-        h8 fB[NT][2];
-        f16x D2[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (nt >= nq) break;
-            to_frags(hT[nt], fB[nt]);
-            D2[nt] = zero16();
-        }
-        h8 w1a = W1[lane], w1b = W1[64 + lane], w2a = W2[lane], w2b = W2[64 + lane];
-        for (int c = 0; c < P.ff_chunks; ++c) {
-            // prefetch the next chunk's weights while this one is multiplied
-            const int cn = c + 1 < P.ff_chunks ? c + 1 : c;
-            const h8 n1a = W1[(long long)cn * 128 + lane], n1b = W1[(long long)cn * 128 + 64 + lane];
-            const h8 n2a = W2[(long long)cn * 128 + lane], n2b = W2[(long long)cn * 128 + 64 + lane];
-            float bias[16];
-            {
-                const float *q = b1 + (long long)c * 32 + hi * 16;
-#pragma unroll
-                for (int a = 0; a < 16; ++a) bias[a] = q[a];
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (nt >= nq) break;
-                f16x d1 = mfma(w1b, fB[nt][1], mfma(w1a, fB[nt][0], zero16()));
-                h8 F[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        // Linear output in fp16, then ReLU
-                        const _Float16 u = (_Float16)(d1[8 * s + j] + bias[8 * s + j]);
-                        F[s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
-                    }
-                D2[nt] = mfma(w2b, F[1], mfma(w2a, F[0], D2[nt]));
-            }
-            w1a = n1a; w1b = n1b; w2a = n2a; w2b = n2b;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (nt >= nq) break;
-            add_rows(D2[nt], b2, hi);
-            round_fp16(D2[nt]);
-#pragma unroll
-            for (int a = 0; a < 16; ++a) hT[nt][a] += D2[nt][a];
-            layer_norm(hT[nt], g2, be2, hi);
-        }
-    }
+    for (int layer = 0; layer + 1 < P.n_layers; ++layer)
+        encoder_layer<NHEAD, NT>(hT, P, layer, lane, n, hi);
+    encoder_layer<NHEAD, 1>(hT, P, P.n_layers - 1, lane, n, hi);
 
     // ---- head on the CLS position (token 0 = tile 0, lane column 0 of both halves)
     float dot = 0.f;
