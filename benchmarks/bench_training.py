@@ -85,10 +85,17 @@ def _instrument_oracle(env, phases):
     def timed_forward(x):
         with phases.span('oracle_transformer'):
             return forward(x)
+    net = orc.net                     # the fused kernel (oracles/fused_net.py), if in use
+
+    def timed_net(x):
+        with phases.span('oracle_transformer'):
+            return net(x)
     orc._resample, orc.model.forward = timed_resample, timed_forward
+    if net is not None:
+        orc.net = timed_net
 
     def restore():
-        orc._resample, orc.model.forward = resample, forward
+        orc._resample, orc.model.forward, orc.net = resample, forward, net
         return rows
     return restore
 
@@ -188,6 +195,8 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
            else 'BASELINE configs[2]', 'W': W, 'hidden': hidden, 'n_actor': n_actor,
            'batch': batch, 'graph': bool(graph), 'data_parallel': bool(data_parallel),
            'policy': policy, 'lr': lr,
+           'oracle_net': ('fused kernel' if getattr(env._oracle, 'net', None) is not None
+                          else 'torch module under autocast') if oracle else None,
            'fused_learner': os.environ.get('TTL_FUSED_LEARNER', '1') != '0'}
 
     def reset():

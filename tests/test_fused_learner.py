@@ -534,3 +534,34 @@ def test_replay_sample_kernel_draws_distinct_uniform_rows():
     assert 850 < chi2 < 1150, chi2                      # 999 degrees of freedom: 999 +- 45
     chi2_first = float(((first.double() - 3.0) ** 2 / 3.0).sum())
     assert 850 < chi2_first < 1150, chi2_first          # position 0 alone is uniform too
+
+
+@pytest.mark.gpu
+def test_policy_sampling_with_the_fused_head_equals_the_module_path(monkeypatch):
+    """`SACActorCritic.select_action` on the GPU runs the actor's head as one
+    `ttl_thin_forward` launch: same actions as the Linear + clamp + exp + randn +
+    tanh chain (same draw: one `randn` of the same shape) to float32 rounding,
+    for probabilistic 0, 1 and in between, and a row's action does not depend
+    on the rows it shares a batch with."""
+    from tracktolearn_amd.algorithms.shared.offpolicy import SACActorCritic
+    torch.manual_seed(3)
+    ac = SACActorCritic(327, 3, '256-128', torch.device(DEV))
+    x = torch.randn(1000, 327, device=DEV)
+    for prob in (0.0, 1.0, 0.4):
+        monkeypatch.setenv('TTL_FUSED_POLICY_HEAD', '1')
+        torch.manual_seed(9)
+        with torch.no_grad():
+            a_fused = ac.select_action(x, prob)
+        monkeypatch.setenv('TTL_FUSED_POLICY_HEAD', '0')
+        torch.manual_seed(9)
+        with torch.no_grad():
+            a_plain = ac.select_action(x, prob)
+        assert a_fused.shape == a_plain.shape == (1000, 3)
+        assert float((a_fused - a_plain).abs().max()) <= 2e-6, prob
+    monkeypatch.setenv('TTL_FUSED_POLICY_HEAD', '1')
+    with torch.no_grad():
+        whole = ac.select_action(x, 0.0)
+        part = ac.select_action(x[17:29].contiguous(), 0.0)
+    # hidden-layer GEMMs may pick other kernels for other batch sizes; the head is row-local
+    assert float((whole[17:29] - part).abs().max()) <= 2e-6
+    assert ac.select_action(x[:0], 1.0).shape == (0, 3)

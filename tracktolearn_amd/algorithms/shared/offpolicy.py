@@ -112,6 +112,11 @@ class MaxEntropyActor(Actor):
         with the default networks a tracking step is bound by exactly those
         launches.  ``probabilistic == 0`` gives ``tanh(mu)`` (``eps * 0`` adds
         nothing) and draws no random numbers."""
+        if state.is_cuda and state.dim() == 2 and not torch.is_grad_enabled() and \
+                state.dtype == torch.float32 and self.action_dim <= 4 and \
+                os.environ.get('TTL_FUSED_POLICY_HEAD', '1') != '0' and \
+                not int(os.environ.get('TTL_POLICY_TILE_ROWS', '0') or 0):
+            return self._sample_fused_head(state, probabilistic)
         p = mlp_inference(self.layers, state)
         mu = p[:, :self.action_dim]
         if not probabilistic:
@@ -119,6 +124,37 @@ class MaxEntropyActor(Actor):
         log_std = torch.clamp(p[:, self.action_dim:], LOG_STD_MIN, LOG_STD_MAX)
         std = torch.exp(log_std) * probabilistic
         return self.output_activation(mu + torch.randn_like(mu) * std)
+
+    def _sample_fused_head(self, state, probabilistic):
+        """``sample`` on the GPU with the head -- the 2A-wide Linear, clamp, exp, the
+        gaussian draw and tanh -- as ONE launch of ``ttl_thin_forward`` (include/
+        ttl_learner.h; the kernel the learner's update uses) instead of a GEMM
+        with N = 6 and seven element-wise kernels.  Same formula: tanh(mu + eps
+        * probabilistic * exp(clamp(log_std))), one ``randn`` of the same shape
+        (none for probabilistic = 0); every row is computed on its own, so a
+        row's action does not depend on its batch."""
+        from tracktolearn_amd.algorithms.shared.fused import HEAD_SAC, HipOps
+        mods = list(self.layers)
+        head = mods[-1]
+        x = _mlp_inference(nn.Sequential(*mods[:-1]), state) if len(mods) > 1 else state
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        n, a = x.shape[0], self.action_dim
+        ops = getattr(self, '_head_ops', None)
+        if ops is None or ops.index != (x.device.index or 0):
+            ops = self._head_ops = HipOps(x.device)
+        if probabilistic:
+            eps = torch.randn((n, a), dtype=torch.float32, device=x.device)
+            if probabilistic != 1.0:
+                eps = eps * probabilistic
+        else:
+            eps = torch.zeros((n, a), dtype=torch.float32, device=x.device)
+        out = torch.empty((n, a), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(n * (a + 1), dtype=torch.float32, device=x.device)
+        if n:
+            ops.thin_forward(x, head.weight.detach(), head.bias.detach(), 2 * a, False, HEAD_SAC,
+                             out, a, eps=eps, logp=scratch[:n], ls_raw=scratch[n:].view(n, a))
+        return out
 
 
 class Critic(nn.Module):
