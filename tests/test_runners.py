@@ -488,7 +488,7 @@ def test_bench_config5_leg():
     assert ph['env_step'] > ph['oracle_transformer']
     # the stopping criterion scores every active streamline of a step, the
     # bonus the ones that stopped: more rows scored than one batch per episode
-    assert c5['oracle_rows_scored_per_step'] > 100
+    assert c5['oracle_rows_scored_per_step'] > 20
     assert c5['whole_batch_on_one_gpu']['n_actor'] == 32768
     assert line['config5_value'] == c5['value']
 
