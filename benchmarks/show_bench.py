@@ -34,11 +34,33 @@ if isinstance(j.get('other_shapes'), dict):
             print(f"{name}: {o['error']}")
             continue
         print(f"{name}: {o['value'] / 1e6:.1f} M ({o['ms_per_step'] * 1e3:.1f} us/step, k_state {o['k_state_ms']:.4f} ms; {o['loop']})")
-t = j.get('config3_training')
-if isinstance(t, dict) and 'error' in t:
-    print('config 3 training step:', t['error'])
-elif isinstance(t, dict):
-    g = t.get('graphed_update') or {}
-    print(f"config 3 training step: {t['train_step_ms']:.2f} ms ({t['train_streamline_steps_per_s'] / 1e6:.1f} M streamline-steps/s), "
-          f"update alone {t['update_ms']:.2f} ms, sample {t['sample_ms']:.3f} ms"
-          + (f"; graphed update: step {g['train_step_ms']:.2f} ms, update {g['update_ms']:.2f} ms" if g else ''))
+def training(name, t):
+    if isinstance(t, dict) and 'error' in t:
+        print(f'{name}:', t['error'])
+    elif isinstance(t, dict):
+        g = t.get('graphed_update') or {}
+        roof = t.get('roofline') or {}
+        ph = t.get('phases_ms_per_step') or {}
+        print(f"{name}: {t['train_step_ms']:.2f} ms per step at n_actor {t['n_actor']} "
+              f"({t['train_streamline_steps_per_s'] / 1e6:.1f} M streamline-steps/s), update alone "
+              f"{t['update_ms']:.2f} ms = {roof.get('achieved', 0):.1f} TF/s = "
+              f"{roof.get('frac', 0):.3f} of the fp32 MFMA peak"
+              + (f"; graphed update: step {g['train_step_ms']:.2f} ms, update {g['update_ms']:.2f} ms"
+                 if g else ''))
+        print('   phases (ms): ' + ', '.join(f'{k} {v:.3f}' for k, v in ph.items()))
+        if 'oracle_rows_scored_per_step' in t:
+            print(f"   oracle: {t['oracle_rows_scored_per_step']:.0f} rows scored per step in "
+                  f"{t['oracle_batches_per_step']:.2f} batches ({t.get('oracle_net')})")
+        w = t.get('whole_batch_on_one_gpu')
+        if w:
+            print(f"   whole batch on one GPU ({w['n_actor']}): {w['train_step_ms']:.2f} ms per step, "
+                  f"{w['train_streamline_steps_per_s'] / 1e6:.1f} M streamline-steps/s")
+
+
+training('config 3 training step', j.get('config3_training'))
+training('config 5 training step', j.get('config5'))
+c = j.get('cpu_baseline')
+if isinstance(c, dict):
+    a = c.get('all_cores') or {}
+    print(f"cpu baseline: {c['value'] / 1e3:.0f} k/s on 1 core; {a.get('value', 0) / 1e6:.2f} M/s on "
+          f"{a.get('cores')} cores ({c.get('cpu_model')})")

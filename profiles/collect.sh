@@ -1,6 +1,6 @@
 #!/bin/bash
 # The judged profile set, from one box and one invocation:
-#   gpurun --timeout 1100 -- 'bash profiles/collect.sh r03'
+#   gpurun --timeout 1150 -- 'bash profiles/collect.sh r04'
 # Profiled passes run ONE leg of bench.py at a time (`--legs`, the same timed
 # windows; without the forked CPU workers and without the episode-to-exhaustion
 # tail whose small launches would dilute the per-kernel averages):
@@ -45,6 +45,16 @@ for leg in weak hbm; do
   cp profiles/${tag}${sfx}_kernel_stats.csv profiles/${tag}${sfx}_pmc_traffic.txt profiles/$js $R/
   rm -rf $O/stats$sfx $O/fetch$sfx $O/write$sfx $O/fetch$sfx.rows $O/write$sfx.rows $O/stats$sfx.rows
 done
-$T python3 bench.py > $O/bench.json
+# round 4: the learner leg (config 3's training step; SACAuto.update alone over 30 updates)
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/learner -- python3 benchmarks/bench_training.py --config c3 > $O/learner.json 2> $O/learner.log
+cp $(find $O/learner -name "*kernel_stats.csv" | head -1) $R/${tag}_learner_kernel_stats.csv
+python3 profiles/learner_trace.py $O/learner > $R/${tag}_learner_update_trace.txt
+tail -1 $O/learner.json > $R/${tag}_learner_under_rocprof.json
+rm -rf $O/learner
+# ... and the oracle network (config 5): fused kernel against the autocast module, counters
+$T python3 benchmarks/bench_oracle_net.py > $R/${tag}_oracle_net_bench.jsonl 2> /dev/null
+bash profiles/collect_pmc_oracle_net.sh $tag > /dev/null 2>&1 || true
+cp profiles/${tag}_pmc_oracle_net.txt $R/ 2> /dev/null || true
+timeout -k 10 900 python3 bench.py > $O/bench.json
 cp $O/bench.json $R/${tag}_bench.json
 python3 benchmarks/show_bench.py $R/${tag}_bench.json
