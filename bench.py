@@ -854,8 +854,10 @@ def main(argv=None):
             c5_total = int(os.environ.get('TTL_BENCH_C5_TOTAL', 131072))
             shard = c5_total // 8 if world == 1 else -(-c5_total // world)
             grp.barrier()
-            c5 = training_measure('c5', n_actor=shard, device=device,
-                                  data_parallel=world > 1, seed_offset=rank)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):     # stdout is the one JSON line
+                c5 = training_measure('c5', n_actor=shard, device=device,
+                                      data_parallel=world > 1, seed_offset=rank)
             grp.barrier()
             # whole job: the slowest rank's step, every rank's streamline-steps
             ms = float(grp.reduce([c5['train_step_ms']], 'max')[0])
@@ -865,7 +867,8 @@ def main(argv=None):
             c5['n_actor_total'] = shard * world
             if world == 1:
                 torch.cuda.empty_cache()
-                whole = training_measure('c5', n_actor=c5_total, device=device)
+                with contextlib.redirect_stdout(sys.stderr):
+                    whole = training_measure('c5', n_actor=c5_total, device=device)
                 c5['whole_batch_on_one_gpu'] = {
                     k: whole[k] for k in ('n_actor', 'update_ms', 'train_step_ms',
                                           'train_rows_per_step', 'train_streamline_steps_per_s',

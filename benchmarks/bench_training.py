@@ -222,10 +222,12 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
             state, _ = env.harvest()
         return state, n
 
-    # fill the ring, first-call costs, graph capture; with the oracle a whole
-    # untimed episode (its GEMM shapes follow the number of rows scored)
+    # fill the ring, first-call costs, graph capture: the same `steps` steps once
+    # untimed -- the policy's (and the oracle's) GEMM shapes follow the number of
+    # active rows, and hipBLASLt picks its kernel for every new row count once
+    # (a few hundred us of host time each; a training run meets every count again)
     state = reset()
-    for _ in range(steps if oracle else 4):
+    for _ in range(steps):
         state, _ = one_step(state)
     # SACAuto.update alone
     b = alg.replay_buffer.sample(batch)
