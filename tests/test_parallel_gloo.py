@@ -101,7 +101,7 @@ def test_ragged_all_gather_world2_gloo():
     assert sorted(results) == [(0, 'ok'), (1, 'ok')], results
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, fused=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -111,6 +111,11 @@ def _dp_worker(rank, world, port, q):
         torch.manual_seed(100 + rank)            # different initial weights
         alg = SACAuto(W, 3, '32-32', n_actors=8, batch_size=B, replay_size=100,
                       rng=None, device=torch.device('cpu'))
+        if fused:
+            # the GPU learner's schedule (shared/fused.py: one all-reduce per gradient
+            # arena) with the kernels replaced by their torch restatement
+            from ref_learner_ops import TorchOps
+            alg._fused_ops = TorchOps()
         alg.enable_data_parallel()
         g = torch.Generator().manual_seed(7)
         full = [torch.randn(2 * B, W, generator=g),
@@ -127,6 +132,7 @@ def _dp_worker(rank, world, port, q):
         mine = [t[rank * B:(rank + 1) * B] for t in full]     # this rank's half
         for _ in range(3):
             alg.update(mine)
+        assert (alg._fused is not None) == fused
         flat = torch.cat([p.detach().reshape(-1) for p in
                           list(alg.agent.actor.parameters()) +
                           list(alg.agent.critic.parameters()) +
@@ -138,15 +144,21 @@ def _dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_learner_world2_gloo():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_data_parallel_learner_world2_gloo(fused):
     """Two learner replicas on half batches each == one learner on the whole
     batch: identical replicas, and equal (to rounding) to the single-process
-    update started from rank 0's weights."""
+    update started from rank 0's weights.  `fused`: the replicas run the GPU
+    learner's hand-scheduled update (arena all-reduce, deterministic
+    reductions), the single process the autograd formulation."""
     from tracktolearn_amd.algorithms.sac_auto import SACAuto
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + os.getpid() % 2000 + (37 if fused else 0)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, fused)) for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=180) for _ in procs)
