@@ -274,9 +274,9 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
     if fl is not None and data_parallel:
         ar_orig = fl._all_reduce
 
-        def timed_all_reduce():
+        def timed_all_reduce(*extra):
             with ph.span('update_all_reduce'):
-                ar_orig()
+                ar_orig(*extra)
         fl._all_reduce = timed_all_reduce
     state = reset()
     torch.cuda.synchronize()

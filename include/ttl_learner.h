@@ -155,13 +155,37 @@ TTL_API int ttl_colsum_finalize(const ttl_colsum_seg *segs, int32_t n_segs, void
  *   du_i   = (alpha / n) 2 pi_i + dpi_i (1 - pi_i^2)
  *   d_head[m][i]         = du_i                                    (d mu)
  *   d_head[m][n_act + i] = [-20 <= log_std_raw <= 2] (du_i eps_i std_i - alpha / n)
- * alpha as in ttl_sac_losses, n = n_rows.  d_head: [n_rows][2 * n_act]. */
+ * alpha as in ttl_sac_losses, n = n_rows.  d_head: [n_rows][2 * n_act].
+ *
+ * head = TTL_HEAD_TANH (the deterministic actor of TD3 / DDPG, td3.py:213-216,
+ * ddpg.py:285-288: actor_loss = -Q1(s, tanh(actor(s))).mean(), d_out of the
+ * critic's head = -1 / n): d_head[m][i] = dpi_i (1 - pi_i^2), d_head:
+ * [n_rows][n_act]; eps, log_std_raw, log_alpha unused. */
 TTL_API int ttl_sac_actor_head_backward(const float *dh, int64_t ld_dh, const float *h,
                                         int64_t ld_h, const float *wa, int32_t n_rows,
-                                        int32_t n_cols, int32_t n_act, const float *pi,
-                                        int64_t ld_pi, const float *eps,
+                                        int32_t n_cols, int32_t n_act, int32_t head,
+                                        const float *pi, int64_t ld_pi, const float *eps,
                                         const float *log_std_raw, const float *log_alpha,
                                         float alpha_const, float *d_head, void *hip_stream);
+
+/* The critic loss of TD3 / DDPG (td3.py:147-176, ddpg.py:254-270): q_online,
+ * q_target: [n][n_q] (n_q = 2: the double critic, 1: DDPG's single one),
+ *   target = r + not_done gamma min_k q_target_k
+ *   dq[i][k] = 2 (q_k - target) / n
+ * loss_part[block][8] = {0, (q1-target)^2, (q2-target)^2, q1, q2, target, 0, 0}
+ * sums per block of 256 rows (NULL to skip); Adam step counters as in
+ * ttl_sac_losses. */
+TTL_API int ttl_td3_losses(const float *q_online, const float *q_target, const float *reward,
+                           const float *not_done, int32_t n, int32_t n_q, float gamma,
+                           float *dq, float *loss_part, float *steps, float *adam_consts,
+                           double *beta_pows, int32_t n_opt, uint32_t tick_mask, double lr,
+                           double beta1, double beta2, void *hip_stream);
+
+/* target = target (1 - tau) + p tau over a flat arena (ddpg.py:300-317) when the
+ * Polyak average is not taken in the same pass as the Adam step (TD3 averages
+ * the critics' targets only every `agent_freq`-th update, td3.py:205-230). */
+TTL_API int ttl_polyak_average(float *target, const float *p, int64_t n, double tau,
+                               void *hip_stream);
 
 /* torch.optim.Adam's step (amsgrad off, weight decay 0, maximize off) over a
  * flat arena of n parameters, fused with the Polyak average of the target

@@ -141,8 +141,13 @@ class TorchOps:
             out.view(-1)[:n] = part[:, off:off + n].sum(0) * scale
 
     def actor_head_backward(self, dh, h, wa, n_act, pi, ld_pi, eps, ls_raw, log_alpha,
-                            alpha_const, d_head):
+                            alpha_const, d_head, head=HEAD_SAC):
         n = dh.shape[0]
+        if head == HEAD_TANH:
+            g = torch.where(h > 0, dh, torch.zeros_like(dh))
+            t = pi[:, :n_act]
+            d_head[:, :n_act] = (g @ wa.t()) * (1 - t * t)
+            return
         alpha = torch.exp(log_alpha.detach()) if log_alpha is not None else alpha_const
         g = torch.where(h > 0, dh, torch.zeros_like(dh))
         dpi = g @ wa.t()
@@ -155,6 +160,32 @@ class TorchOps:
         d_head[:, :n_act] = du
         d_head[:, n_act:] = torch.where(inside, du * (eps[:n] * std) - an,
                                         torch.zeros_like(du))
+
+    def td3_losses(self, q_on, q_tg, reward, not_done, gamma, dq, loss_part, steps, consts,
+                   beta_pows, tick_mask, lr):
+        n, n_q = q_on.shape
+        tq = q_tg.min(dim=1).values
+        target = reward + not_done * gamma * tq
+        e = q_on - target[:, None]
+        dq[:] = 2 * e / n
+        if loss_part is not None:
+            z = torch.zeros_like(target)
+            e2 = e[:, 1] ** 2 if n_q == 2 else z
+            q2 = q_on[:, 1] if n_q == 2 else z
+            terms = torch.stack([z, e[:, 0] ** 2, e2, q_on[:, 0], q2, target, z, z], dim=1)
+            pad = (-n) % LOSS_BLOCK
+            terms = torch.cat([terms, terms.new_zeros(pad, 8)])
+            loss_part[:] = terms.view(-1, LOSS_BLOCK, 8).sum(1)
+        for k in range(steps.numel()):
+            if (tick_mask >> k) & 1:
+                steps[k] += 1
+                beta_pows[2 * k] *= BETA1
+                beta_pows[2 * k + 1] *= BETA2
+                consts[2 * k] = lr / (1 - float(beta_pows[2 * k]))
+                consts[2 * k + 1] = math.sqrt(1 - float(beta_pows[2 * k + 1]))
+
+    def polyak(self, target, p, tau):
+        target.mul_(1 - tau).add_(p * tau)
 
     @staticmethod
     def _adam(p, g, m, v, consts):

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in ('ttl_hip.h', 'ttl_learner.h'):
         header = open(os.path.join(ROOT, 'include', name)).read()
         body = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
-        declared |= set(re.findall(r'\b(ttl_[a-z_]+)\s*\(', body))
+        declared |= set(re.findall(r'\b(ttl_[a-z0-9_]+)\s*\(', body))
     assert declared, 'no declarations parsed'
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     lib = _lib.load()

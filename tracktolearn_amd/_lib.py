@@ -169,8 +169,15 @@ SYMBOLS = {
     'ttl_colsum_finalize': (C.c_int, [C.POINTER(ColsumSeg), C.c_int32, C.c_void_p]),
     'ttl_sac_actor_head_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+                                              C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                              C.c_void_p]),
+    'ttl_td3_losses': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_double,
+                                 C.c_double, C.c_double, C.c_void_p]),
+    'ttl_polyak_average': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
+                                     C.c_void_p]),
     'ttl_adam_polyak': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                   C.c_double, C.c_void_p]),

@@ -8,6 +8,7 @@ from the env kernels into the device replay ring and batches are gathered on
 the device.
 """
 import copy
+import os
 from collections import defaultdict
 
 import torch
@@ -59,6 +60,26 @@ class DDPG(RLAlgorithm):
         #: data-parallel replicas (SAC.enable_data_parallel); see _schedule
         self._dp = False
         self._dp_group = None
+        #: the hand-scheduled update of shared/fused.py, built at the first update on
+        #: a CUDA device (there is no fused CPU path); ``_fused_ops`` is the tests' seam
+        #: (a stand-in for the HIP kernels), ``use_fused_learner = False`` /
+        #: ``TTL_FUSED_LEARNER=0`` keep the autograd formulation on the GPU too
+        self._fused = None
+        self._fused_ops = None
+        self.use_fused_learner = os.environ.get('TTL_FUSED_LEARNER', '1') != '0'
+
+    def _fused_class(self):
+        from tracktolearn_amd.algorithms.shared.fused import FusedTD3Update
+        return FusedTD3Update
+
+    def _use_fused(self):
+        if self._fused is not None:
+            return True
+        dev = torch.device(self.device)
+        if self._fused_ops is None and (dev.type != 'cuda' or not self.use_fused_learner):
+            return False
+        self._fused = self._fused_class()(self, ops=self._fused_ops)
+        return True
 
     # ------------------------------------------------------------------ #
     def sample_action(self, state):
@@ -165,6 +186,10 @@ class DDPG(RLAlgorithm):
         then policy ascent through the critic, then Polyak averaging."""
         self.total_it += 1
         state, action, next_state, reward, not_done = batch
+        if self._use_fused():
+            with torch.no_grad():
+                noise = torch.randn_like(action) * (self.action_std * 2)
+                return self._fused.update(batch, noise, update_actor=True)
         with torch.no_grad():
             noise = torch.randn_like(action) * (self.action_std * 2)
             next_action = self.target.actor(next_state) + noise

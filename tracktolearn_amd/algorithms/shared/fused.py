@@ -150,14 +150,28 @@ class HipOps:
                    'ttl_colsum_finalize')
 
     def actor_head_backward(self, dh, h, wa, n_act, pi, ld_pi, eps, ls_raw, log_alpha,
-                            alpha_const, d_head):
+                            alpha_const, d_head, head=HEAD_SAC):
         n_rows, n_cols = dh.shape
         assert h.shape == dh.shape and wa.is_contiguous() and wa.shape == (n_act, n_cols)
         _lib.check(self.lib.ttl_sac_actor_head_backward(
             _ptr(dh), dh.stride(0), _ptr(h), h.stride(0), _ptr(wa), n_rows, n_cols, n_act,
-            _ptr(pi), ld_pi, _ptr(eps), _ptr(ls_raw),
+            head, _ptr(pi), ld_pi, _ptr(eps) if eps is not None else None,
+            _ptr(ls_raw) if ls_raw is not None else None,
             _ptr(log_alpha) if log_alpha is not None else None, float(alpha_const),
             _ptr(d_head), self._s()), 'ttl_sac_actor_head_backward')
+
+    def td3_losses(self, q_on, q_tg, reward, not_done, gamma, dq, loss_part, steps, consts,
+                   beta_pows, tick_mask, lr):
+        n, n_q = q_on.shape
+        _lib.check(self.lib.ttl_td3_losses(
+            _ptr(q_on), _ptr(q_tg), _ptr(reward), _ptr(not_done), n, n_q, float(gamma),
+            _ptr(dq), _ptr(loss_part) if loss_part is not None else None, _ptr(steps),
+            _ptr(consts), _ptr(beta_pows), steps.numel(), tick_mask, float(lr), BETA1, BETA2,
+            self._s()), 'ttl_td3_losses')
+
+    def polyak(self, target, p, tau):
+        _lib.check(self.lib.ttl_polyak_average(_ptr(target), _ptr(p), p.numel(), float(tau),
+                                               self._s()), 'ttl_polyak_average')
 
     def adam_polyak(self, p, g, m, v, target, consts, tau):
         _lib.check(self.lib.ttl_adam_polyak(
@@ -220,40 +234,46 @@ class _Arena:
         return flat[off:off + n].view(shape)
 
 
-class FusedSACUpdate:
-    """One SAC / SACAuto update on ``alg``'s networks (see the module
-    docstring).  ``alg`` is a ``tracktolearn_amd.algorithms.sac.SAC`` (or
-    ``SACAuto``); the parameters of ``alg.agent`` / ``alg.target`` and the
-    state of its optimizers are re-homed into the arenas on construction."""
+class _FusedNets:
+    """What the hand-scheduled updates share: the actor and the critic(s) of
+    ``alg.agent`` / ``alg.target`` re-homed into arenas (parameters, gradients,
+    Adam moments as views), the optimizers' state bound to them, the device-side
+    Adam step counters."""
 
-    def __init__(self, alg, ops=None):
+    #: (optimizer attribute, arena attribute) in the order of the step counters
+    OPTIMIZERS = (('actor_optimizer', 'arena_a'), ('critic_optimizer', 'arena_q'))
+
+    def __init__(self, alg, ops, head_out):
         self.alg = alg
         self.device = torch.device(alg.device)
         self.ops = ops if ops is not None else HipOps(self.device)
         actor, critic = alg.agent.actor, alg.agent.critic
+        tcritic = alg.target.critic
         self.a_lin = _linears(actor.layers)
-        self.q_lin = [_linears(critic.q1), _linears(critic.q2)]
         self.ta_lin = _linears(alg.target.actor.layers)
-        self.tq_lin = [_linears(alg.target.critic.q1), _linears(alg.target.critic.q2)]
+        names = ['q1'] + (['q2'] if hasattr(critic, 'q2') else [])
+        self.q_lin = [_linears(getattr(critic, n)) for n in names]
+        self.tq_lin = [_linears(getattr(tcritic, n)) for n in names]
+        self.NQ = len(names)
         if self.a_lin is None or None in self.q_lin:
-            raise ValueError('FusedSACUpdate needs Linear/ReLU stacks (make_fc_network)')
+            raise ValueError('the fused update needs Linear/ReLU stacks (make_fc_network)')
         self.S = self.a_lin[0].in_features
-        self.A = alg.agent.actor.action_dim
+        self.A = actor.action_dim
         self.L = len(self.a_lin) - 1                         # hidden layers
         self.ha = [lin.out_features for lin in self.a_lin[:-1]]
         self.hq = [lin.out_features for lin in self.q_lin[0][:-1]]
-        ok = len(self.q_lin[0]) == len(self.q_lin[1]) == self.L + 1 and \
-            self.a_lin[-1].out_features == 2 * self.A and self.A <= 4 and \
+        ok = all(len(q) == self.L + 1 for q in self.q_lin) and \
+            self.a_lin[-1].out_features == head_out and self.A <= 4 and \
             self.q_lin[0][0].in_features == self.S + self.A and \
-            all(a.weight.shape == b.weight.shape for a, b in zip(*self.q_lin)) and \
+            all(a.weight.shape == b.weight.shape for q in self.q_lin[1:]
+                for a, b in zip(self.q_lin[0], q)) and \
             self.q_lin[0][-1].out_features == 1
         if not ok:
-            raise ValueError('FusedSACUpdate: unsupported network shapes')
+            raise ValueError('the fused update: unsupported network shapes')
         #: float32 on the GPU; the CPU schedule test also runs it in float64
         self.dtype = self.a_lin[0].weight.dtype
         if isinstance(self.ops, HipOps) and self.dtype != torch.float32:
-            raise ValueError('FusedSACUpdate: the HIP kernels are float32')
-        self.auto = hasattr(alg, 'log_alpha')
+            raise ValueError('the fused update: the HIP kernels are float32')
         self._build_arenas()
         self._batch = None
         self.steps = torch.zeros(3, dtype=self.dtype, device=self.device)
@@ -262,7 +282,6 @@ class FusedSACUpdate:
         self.beta_pows = torch.ones(6, dtype=torch.float64, device=self.device)
         self._bind_optimizers()
         self.loss_out = torch.zeros(8, dtype=self.dtype, device=self.device)
-        self.mean_logp = torch.zeros(1, dtype=self.dtype, device=self.device)
 
     # ------------------------------------------------------------------ #
     # arenas
@@ -275,14 +294,18 @@ class FusedSACUpdate:
         q_slots = []
         for l, lin in enumerate(self.q_lin[0]):
             o, i = lin.weight.shape
-            q_slots += [(f'w{l}', (2, o, i)), (f'b{l}', (2, o))]
+            q_slots += [(f'w{l}', (self.NQ, o, i)), (f'b{l}', (self.NQ, o))]
         self.arena_q = _Arena(q_slots, dev, self.dtype)
-        self._home(self.arena_a, 'online', [self.a_lin])
-        self._home(self.arena_a, 'target', [self.ta_lin])
-        self._home(self.arena_q, 'online', self.q_lin)
-        self._home(self.arena_q, 'target', self.tq_lin)
+        self._rehome()
 
-    def _home(self, arena, which, nets):
+    def _tables(self):
+        """(arena, which, networks, stacked) of the four parameter sets."""
+        return ((self.arena_a, 'online', [self.a_lin], False),
+                (self.arena_a, 'target', [self.ta_lin], False),
+                (self.arena_q, 'online', self.q_lin, True),
+                (self.arena_q, 'target', self.tq_lin, True))
+
+    def _home(self, arena, which, nets, stacked):
         """Move the parameters of ``nets`` (one list of Linears per network)
         into ``arena.<which>`` and make them views of it; online parameters
         get their ``.grad`` as a view of ``arena.grad``."""
@@ -291,55 +314,57 @@ class FusedSACUpdate:
             for l, lin in enumerate(lins):
                 for name, p in ((f'w{l}', lin.weight), (f'b{l}', lin.bias)):
                     v = arena.view(flat, name)
-                    v = v[k] if len(nets) > 1 else v
+                    v = v[k] if stacked else v
                     v.copy_(p.data)
                     p.data = v
                     if which == 'online':
                         g = arena.view(arena.grad, name)
-                        p.grad = g[k] if len(nets) > 1 else g
+                        p.grad = g[k] if stacked else g
 
     def _homed(self):
         """Whether the parameters still are views of the arenas (``.to()`` /
         ``.float()`` on a module re-allocates them)."""
         a, q = self.arena_a, self.arena_q
+        k = self.NQ - 1
         return (self.a_lin[0].weight.data_ptr() == a.view(a.online, 'w0').data_ptr() and
-                self.q_lin[1][-1].bias.data_ptr() == q.view(q.online, f'b{self.L}')[1].data_ptr()
+                self.q_lin[k][-1].bias.data_ptr() == q.view(q.online, f'b{self.L}')[k].data_ptr()
                 and self.ta_lin[0].weight.data_ptr() == a.view(a.target, 'w0').data_ptr() and
-                self.tq_lin[1][-1].bias.data_ptr() ==
-                q.view(q.target, f'b{self.L}')[1].data_ptr())
+                self.tq_lin[k][-1].bias.data_ptr() ==
+                q.view(q.target, f'b{self.L}')[k].data_ptr())
 
     def _rehome(self):
-        self._home(self.arena_a, 'online', [self.a_lin])
-        self._home(self.arena_a, 'target', [self.ta_lin])
-        self._home(self.arena_q, 'online', self.q_lin)
-        self._home(self.arena_q, 'target', self.tq_lin)
+        for arena, which, nets, stacked in self._tables():
+            self._home(arena, which, nets, stacked)
 
     def _attach_grads(self):
         """``optimizer.zero_grad()`` (set_to_none) detaches ``.grad``."""
-        for arena, nets in ((self.arena_a, [self.a_lin]), (self.arena_q, self.q_lin)):
+        for arena, which, nets, stacked in self._tables():
+            if which != 'online':
+                continue
             for k, lins in enumerate(nets):
                 for l, lin in enumerate(lins):
                     for name, p in ((f'w{l}', lin.weight), (f'b{l}', lin.bias)):
                         if p.grad is None or p.grad.data_ptr() == 0:
                             g = arena.view(arena.grad, name)
-                            p.grad = g[k] if len(nets) > 1 else g
+                            p.grad = g[k] if stacked else g
 
     # ------------------------------------------------------------------ #
     # optimizer state as views of the arenas
     def _bind_optimizers(self):
         alg = self.alg
-        table = [(alg.actor_optimizer, self.arena_a, [self.a_lin], 1),
-                 (alg.critic_optimizer, self.arena_q, self.q_lin, 2)]
-        for opt, arena, nets, k_opt in table:
+        table = [(alg.actor_optimizer, self.arena_a, [self.a_lin], 1, False),
+                 (alg.critic_optimizer, self.arena_q, self.q_lin, 2, True)]
+        for opt, arena, nets, k_opt, stacked in table:
             for k, lins in enumerate(nets):
                 for l, lin in enumerate(lins):
                     for name, p in ((f'w{l}', lin.weight), (f'b{l}', lin.bias)):
                         self._bind_state(opt, p, k_opt,
-                                         *(arena.view(f, name)[k] if len(nets) > 1
+                                         *(arena.view(f, name)[k] if stacked
                                            else arena.view(f, name) for f in (arena.m, arena.v)))
-        if self.auto:
-            self.alpha_m = torch.zeros(1, dtype=self.dtype, device=self.device)
-            self.alpha_v = torch.zeros(1, dtype=self.dtype, device=self.device)
+        if getattr(self, 'auto', False):
+            if not hasattr(self, 'alpha_m'):
+                self.alpha_m = torch.zeros(1, dtype=self.dtype, device=self.device)
+                self.alpha_v = torch.zeros(1, dtype=self.dtype, device=self.device)
             self._bind_state(alg.alpha_optimizer, alg.log_alpha, 0, self.alpha_m, self.alpha_v)
             if alg.log_alpha.grad is None:
                 alg.log_alpha.grad = torch.zeros_like(alg.log_alpha)
@@ -374,15 +399,50 @@ class FusedSACUpdate:
     def _optimizers_bound(self):
         alg = self.alg
         a, q = self.arena_a, self.arena_q
+        k = self.NQ - 1
         st_a = alg.actor_optimizer.state.get(self.a_lin[0].weight, {})
-        st_q = alg.critic_optimizer.state.get(self.q_lin[1][-1].bias, {})
+        st_q = alg.critic_optimizer.state.get(self.q_lin[k][-1].bias, {})
         ok = ('exp_avg' in st_a and st_a['exp_avg'].data_ptr() == a.view(a.m, 'w0').data_ptr()
               and 'exp_avg' in st_q and
-              st_q['exp_avg'].data_ptr() == q.view(q.m, f'b{self.L}')[1].data_ptr())
-        if ok and self.auto:
+              st_q['exp_avg'].data_ptr() == q.view(q.m, f'b{self.L}')[k].data_ptr())
+        if ok and getattr(self, 'auto', False):
             st = alg.alpha_optimizer.state.get(alg.log_alpha, {})
             ok = 'exp_avg' in st and st['exp_avg'].data_ptr() == self.alpha_m.data_ptr()
         return ok
+
+    def _prepare(self, B):
+        """Before an update: workspaces of the batch size, parameters and
+        optimizer state still at home, gradients attached."""
+        if self._batch != B:
+            self._alloc(B)
+            self._batch = B
+        if not self._homed():
+            self._rehome()
+        if not self._optimizers_bound():
+            self._bind_optimizers()
+        self._attach_grads()
+
+    def _all_reduce(self, extra=()):
+        import torch.distributed as dist
+        group = self.alg._dp_group
+        world = dist.get_world_size(group)
+        for t in (self.arena_a.grad, self.arena_q.grad) + tuple(extra):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            t /= world
+
+
+class FusedSACUpdate(_FusedNets):
+    """One SAC / SACAuto update on ``alg``'s networks (see the module
+    docstring).  ``alg`` is a ``tracktolearn_amd.algorithms.sac.SAC`` (or
+    ``SACAuto``); the parameters of ``alg.agent`` / ``alg.target`` and the
+    state of its optimizers are re-homed into the arenas on construction."""
+
+    def __init__(self, alg, ops=None):
+        self.auto = hasattr(alg, 'log_alpha')
+        super().__init__(alg, ops, 2 * alg.agent.actor.action_dim)
+        if self.NQ != 2:
+            raise ValueError('FusedSACUpdate needs the double critic')
+        self.mean_logp = torch.zeros(1, dtype=self.dtype, device=self.device)
 
     # ------------------------------------------------------------------ #
     # workspaces of a batch size
@@ -432,14 +492,7 @@ class FusedSACUpdate:
         alg, ops = self.alg, self.ops
         state, action, next_state, reward, not_done = batch
         B = state.shape[0]
-        if self._batch != B:
-            self._alloc(B)
-            self._batch = B
-        if not self._homed():
-            self._rehome()
-        if not self._optimizers_bound():
-            self._bind_optimizers()
-        self._attach_grads()
+        self._prepare(B)
         S, A, L, ld = self.S, self.A, self.L, self.ld
         aa, aq = self.arena_a, self.arena_q
         W = lambda arena, flat, l: arena.view(flat, f'w{l}')      # noqa: E731
@@ -549,7 +602,7 @@ class FusedSACUpdate:
 
         # ---- data-parallel replicas: one all-reduce per arena
         if getattr(alg, '_dp', False):
-            self._all_reduce()
+            self._all_reduce((self.mean_logp,) if self.auto else ())
 
         # ---- temperature, actor, critics: Adam (+ Polyak)
         if self.auto:
@@ -592,10 +645,203 @@ class FusedSACUpdate:
                     + B * (mac_dgrad_a + ta) + B * (fa + ta))
         return {'issued': 2.0 * issued, 'autograd': 2.0 * autograd}
 
-    def _all_reduce(self):
+
+class FusedTD3Update(_FusedNets):
+    """One TD3 update (td3.py:130-230) -- or, with the single critic and
+    ``agent_freq`` 1, one DDPG update (ddpg.py:234-319) -- as the same kind of
+    hand-scheduled forward/backward: critic regression on the smoothed target
+    action first, then (every ``agent_freq``-th update) policy ascent through
+    the UPDATED first critic and the Polyak averages.  Rows of ``xs``: [0,B) =
+    (s, a), [B,2B) = (s, pi(s)) (actor pass), [2B,3B) = (s', target action)."""
+
+    def __init__(self, alg, ops=None):
+        super().__init__(alg, ops, alg.agent.actor.action_dim)
+        self.actor_loss = torch.zeros(1, dtype=self.dtype, device=self.device)
+
+    def _alloc(self, B):
+        dev, S, A = self.device, self.S, self.A
+        z = dict(dtype=self.dtype, device=dev)
+        ld = (S + A + 3) // 4 * 4
+        self.B, self.ld = B, ld
+        nq = self.NQ
+        self.xs = torch.zeros(3 * B, ld, **z)
+        self.act_a = [torch.empty(B, h, **z) for h in self.ha]
+
+        def crit(rows, nets):
+            return [torch.empty(rows, nets * h, **z) if l == 0 or nets == 1
+                    else torch.empty(nets, rows, h, **z) for l, h in enumerate(self.hq)]
+        self.hc, self.ht, self.dzc = crit(B, nq), crit(B, nq), crit(B, nq)
+        self.h1 = [torch.empty(B, h, **z) for h in self.hq]      # first critic on (s, pi(s))
+        self.dz1 = [torch.empty(B, h, **z) for h in self.hq]
+        self.q_on, self.q_tg = torch.empty(B, nq, **z), torch.empty(B, nq, **z)
+        self.q_pi = torch.empty(B, 1, **z)
+        self.dq = torch.empty(B, nq, **z)
+        self.dq_pi = torch.full((B, 1), -1.0 / B, **z)
+        self.loss_part = torch.zeros(-(-B // LOSS_BLOCK), 8, **z)
+        self.dza = [torch.empty(B, h, **z) for h in self.ha]
+        self.wa = torch.empty(A, self.hq[0], **z)
+        self.d_head = torch.empty(B, A, **z)
+        R = -(-B // _rows_per_block(B))
+        hqL, haL = self.hq[-1], self.ha[-1]
+        self.part_q_top = torch.zeros(R, 2 * nq * hqL + nq, **z)
+        self.part_q = [torch.zeros(R, nq * h, **z) for h in self.hq[:-1]]
+        self.part_1 = torch.zeros(R, max(2 * hqL + 1, max(self.hq)), **z)   # actor-pass scratch
+        self.part_a_top = torch.zeros(R, haL + A * haL + A, **z)
+        self.part_a = [torch.zeros(R, h, **z) for h in self.ha[:-1]]
+
+    def _critics_forward(self, flat, rows, hbuf, qout):
+        aq, S, A, L, nq = self.arena_q, self.S, self.A, self.L, self.NQ
+        fused = torch._addmm_activation
+        h0 = self.hq[0]
+        fused(aq.view(flat, 'b0').view(nq * h0), rows[:, :S + A],
+              aq.view(flat, 'w0').view(nq * h0, S + A).t(), use_gelu=False, out=hbuf[0])
+        for l in range(1, L):
+            hp = self.hq[l - 1]
+            for k in range(nq):
+                if nq == 1:
+                    prev, out = hbuf[l - 1], hbuf[l]
+                else:
+                    prev = hbuf[0][:, k * hp:(k + 1) * hp] if l == 1 else hbuf[l - 1][k]
+                    out = hbuf[l][k]
+                fused(aq.view(flat, f'b{l}')[k], prev, aq.view(flat, f'w{l}')[k].t(),
+                      use_gelu=False, out=out)
+        self.ops.thin_forward(hbuf[L - 1], aq.view(flat, f'w{L}'), aq.view(flat, f'b{L}').view(nq),
+                              nq, nq > 1, HEAD_PLAIN, qout, nq)
+
+    def update(self, batch, noise, update_actor, want_losses=True):
+        """``noise``: the target-policy smoothing noise (already scaled and, for
+        TD3, clipped); ``update_actor``: whether this update also steps the
+        actor and the targets."""
+        alg, ops = self.alg, self.ops
+        state, action, next_state, reward, not_done = batch
+        B = state.shape[0]
+        self._prepare(B)
+        S, A, L, ld, nq = self.S, self.A, self.L, self.ld, self.NQ
+        aa, aq = self.arena_a, self.arena_q
+        W = lambda arena, flat, l: arena.view(flat, f'w{l}')      # noqa: E731
+        Bv = lambda arena, flat, l: arena.view(flat, f'b{l}')     # noqa: E731
+        fused = torch._addmm_activation
+        xs = self.xs
+        h0 = self.hq[0]
+        clip = getattr(alg, 'noise_clip', None) is not None          # TD3 clamps, DDPG does not
+
+        # ---- inputs; target action = target_actor(s') + noise
+        ops.build_inputs(state, action, next_state, xs, S, A, W(aq, aq.online, 0)[0], self.wa)
+        x = xs[2 * B:, :S]
+        for l in range(L):
+            fused(Bv(aa, aa.target, l), x, W(aa, aa.target, l).t(), use_gelu=False,
+                  out=self.act_a[l])
+            x = self.act_a[l]
+        ops.thin_forward(x, W(aa, aa.target, L), Bv(aa, aa.target, L), A, False, HEAD_TANH,
+                         xs[2 * B:, S:], ld)
+        nxt = xs[2 * B:, S:S + A]
+        nxt.add_(noise)
+        if clip:
+            nxt.clamp_(-alg.max_action, alg.max_action)
+
+        # ---- critics: target on (s', a'), online on (s, a); loss and d loss / d q
+        self._critics_forward(aq.target, xs[2 * B:], self.ht, self.q_tg)
+        self._critics_forward(aq.online, xs[:B], self.hc, self.q_on)
+        ops.td3_losses(self.q_on, self.q_tg, reward, not_done, alg.gamma, self.dq,
+                       self.loss_part if want_losses else None, self.steps, self.consts,
+                       self.beta_pows, 0b110 if update_actor else 0b100, alg.lr)
+
+        # ---- critics backward
+        ops.thin_backward(self.dq, self.hc[L - 1], W(aq, aq.online, L), nq, nq > 1, 0, B,
+                          self.dzc[L - 1], self.part_q_top)
+        for l in range(L - 1, 0, -1):
+            hp = self.hq[l - 1]
+            for k in range(nq):
+                if nq == 1:
+                    dz, a_prev, dz_prev = self.dzc[l], self.hc[l - 1], self.dzc[l - 1]
+                elif l == 1:
+                    cols = slice(k * hp, (k + 1) * hp)
+                    dz, a_prev, dz_prev = self.dzc[l][k], self.hc[0][:, cols], self.dzc[0][:, cols]
+                else:
+                    dz, a_prev, dz_prev = self.dzc[l][k], self.hc[l - 1][k], self.dzc[l - 1][k]
+                torch.mm(dz.t(), a_prev, out=W(aq, aq.grad, l)[k])
+                torch.mm(dz, W(aq, aq.online, l)[k], out=dz_prev)
+            ops.relu_backward_bias(self.dzc[l - 1], self.hc[l - 1], 0, B, self.part_q[l - 1])
+        torch.mm(self.dzc[0].t(), xs[:B, :S + A], out=W(aq, aq.grad, 0).view(nq * h0, S + A))
+        hqL = self.hq[-1]
+        segs = [(self.part_q_top, 0, nq * hqL, Bv(aq, aq.grad, L - 1).view(-1), 1.0),
+                (self.part_q_top, nq * hqL, nq * hqL, W(aq, aq.grad, L).view(-1), 1.0),
+                (self.part_q_top, 2 * nq * hqL, nq, Bv(aq, aq.grad, L).view(-1), 1.0)]
+        segs += [(self.part_q[l], 0, nq * self.hq[l], Bv(aq, aq.grad, l).view(-1), 1.0)
+                 for l in range(L - 1)]
+        if want_losses:
+            segs.append((self.loss_part, 0, 8, self.loss_out, 1.0 / B))
+        ops.colsum_finalize(segs)
+        dp = getattr(alg, '_dp', False)
+        if dp and not update_actor:
+            self._all_reduce_one(aq.grad)
+        if not update_actor:
+            ops.adam_polyak(aq.online, aq.grad, aq.m, aq.v, None, self.consts[4:6], alg.tau)
+            return self._losses(want_losses, False)
+        if dp:
+            self._all_reduce_one(aq.grad)
+        ops.adam_polyak(aq.online, aq.grad, aq.m, aq.v, None, self.consts[4:6], alg.tau)
+
+        # ---- actor pass: pi(s) on rows [B,2B), the UPDATED first critic on (s, pi(s))
+        self.wa.copy_(W(aq, aq.online, 0)[0][:, S:S + A].t())     # its action columns, now
+        x = xs[B:2 * B, :S]
+        for l in range(L):
+            fused(Bv(aa, aa.online, l), x, W(aa, aa.online, l).t(), use_gelu=False,
+                  out=self.act_a[l])
+            x = self.act_a[l]
+        ops.thin_forward(x, W(aa, aa.online, L), Bv(aa, aa.online, L), A, False, HEAD_TANH,
+                         xs[B:2 * B, S:], ld)
+        x = xs[B:2 * B, :S + A]
+        for l in range(L):
+            fused(Bv(aq, aq.online, l)[0], x, W(aq, aq.online, l)[0].t(), use_gelu=False,
+                  out=self.h1[l])
+            x = self.h1[l]
+        ops.thin_forward(x, W(aq, aq.online, L)[0], Bv(aq, aq.online, L)[0], 1, False,
+                         HEAD_PLAIN, self.q_pi, 1)
+        # d(-mean q1) / d q1 = -1 / B down to the action columns of the first layer
+        ops.thin_backward(self.dq_pi, self.h1[L - 1], W(aq, aq.online, L)[0], 1, False, 0, 0,
+                          self.dz1[L - 1], self.part_1)
+        for l in range(L - 1, 0, -1):
+            torch.mm(self.dz1[l], W(aq, aq.online, l)[0], out=self.dz1[l - 1])
+            if l > 1:
+                ops.relu_backward_bias(self.dz1[l - 1], self.h1[l - 1], 0, 0,
+                                       self.part_1[:, :self.hq[l - 1]])
+        ops.actor_head_backward(self.dz1[0], self.h1[0], self.wa, A, xs[B:2 * B, S:], ld, None,
+                                None, None, 0.0, self.d_head, head=HEAD_TANH)
+
+        # ---- actor backward
+        haL = self.ha[-1]
+        ops.thin_backward(self.d_head, self.act_a[L - 1], W(aa, aa.online, L), A, False, 0, B,
+                          self.dza[L - 1], self.part_a_top)
+        for l in range(L - 1, 0, -1):
+            torch.mm(self.dza[l].t(), self.act_a[l - 1], out=W(aa, aa.grad, l))
+            torch.mm(self.dza[l], W(aa, aa.online, l), out=self.dza[l - 1])
+            ops.relu_backward_bias(self.dza[l - 1], self.act_a[l - 1], 0, B, self.part_a[l - 1])
+        torch.mm(self.dza[0].t(), xs[B:2 * B, :S], out=W(aa, aa.grad, 0))
+        segs = [(self.part_a_top, 0, haL, Bv(aa, aa.grad, L - 1), 1.0),
+                (self.part_a_top, haL, A * haL, W(aa, aa.grad, L).view(-1), 1.0),
+                (self.part_a_top, haL + A * haL, A, Bv(aa, aa.grad, L), 1.0)]
+        segs += [(self.part_a[l], 0, self.ha[l], Bv(aa, aa.grad, l), 1.0) for l in range(L - 1)]
+        segs.append((self.q_pi, 0, 1, self.actor_loss, -1.0 / B))
+        ops.colsum_finalize(segs)
+        if dp:
+            self._all_reduce_one(aa.grad)
+        ops.adam_polyak(aa.online, aa.grad, aa.m, aa.v, aa.target, self.consts[2:4], alg.tau)
+        ops.polyak(aq.target, aq.online, alg.tau)
+        return self._losses(want_losses, True)
+
+    def _all_reduce_one(self, t):
         import torch.distributed as dist
         group = self.alg._dp_group
-        world = dist.get_world_size(group)
-        for t in (self.arena_a.grad, self.arena_q.grad) + ((self.mean_logp,) if self.auto else ()):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            t /= world
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t /= dist.get_world_size(group)
+
+    def _losses(self, want, actor):
+        if not want:
+            return {}
+        lo = self.loss_out
+        al = self.actor_loss[0] if actor else 0.0
+        if self.NQ == 2:
+            return {'actor_loss': al, 'critic_loss': lo[1] + lo[2], 'loss_q1': lo[1],
+                    'loss_q2': lo[2], 'Q1': lo[3], 'Q2': lo[4], "Q'": lo[5]}
+        return {'actor_loss': al, 'critic_loss': lo[1], 'Q': lo[3], "Q'": lo[5]}

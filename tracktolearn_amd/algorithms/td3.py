@@ -1,4 +1,5 @@
-"""TD3 (Fujimoto et al. 2018) -- mirror of TrackToLearn/algorithms/td3.py."""
+"""TD3 (Fujimoto et al. 2018) -- mirror of TrackToLearn/algorithms/td3.py.  On
+a CUDA device ``update`` runs as shared/fused.py:FusedTD3Update (as DDPG's)."""
 import torch
 import torch.nn.functional as F
 
@@ -33,6 +34,12 @@ class TD3(DDPG):
         """td3.py:130-230."""
         self.total_it += 1
         state, action, next_state, reward, not_done = batch
+        if self._use_fused():
+            with torch.no_grad():
+                noise = (torch.randn_like(action) * (self.action_std * 2)).clamp(
+                    -self.noise_clip, self.noise_clip)
+                return self._fused.update(batch, noise,
+                                          update_actor=self.total_it % self.agent_freq == 0)
         with torch.no_grad():
             noise = (torch.randn_like(action) * (self.action_std * 2)).clamp(
                 -self.noise_clip, self.noise_clip)

@@ -257,6 +257,76 @@ __global__ __launch_bounds__(LB) void k_sac_losses(LossArgs P) {
     }
 }
 
+struct Td3LossArgs {
+    const float *q_on, *q_tg, *reward, *not_done;
+    int n, n_q;
+    float gamma;
+    float *dq, *loss_part;
+    float *steps, *consts; double *beta_pows; int n_opt; unsigned tick_mask;
+    double lr, beta1, beta2;
+};
+
+__global__ __launch_bounds__(LB) void k_td3_losses(Td3LossArgs P) {
+    const int i = blockIdx.x * LB + threadIdx.x;
+    const float inv_n = 1.f / (float)P.n;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < P.n) {
+        float tq = P.q_tg[P.n_q * i];
+        if (P.n_q == 2) tq = fminf(tq, P.q_tg[2 * i + 1]);
+        // td3.py:160-163 / ddpg.py:262-264: reward + not_done * gamma * target_Q
+        const float target = P.reward[i] + (P.not_done[i] * P.gamma) * tq;
+        const float q1 = P.q_on[P.n_q * i], e1 = q1 - target;
+        P.dq[P.n_q * i] = 2.f * e1 * inv_n;
+        s[1] = e1 * e1; s[3] = q1; s[5] = target;
+        if (P.n_q == 2) {
+            const float q2 = P.q_on[2 * i + 1], e2 = q2 - target;
+            P.dq[2 * i + 1] = 2.f * e2 * inv_n;
+            s[2] = e2 * e2; s[4] = q2;
+        }
+    }
+    if (P.loss_part) {
+        __shared__ float red[NW][6];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float t = wave_sum(s[k]);
+            if (lane == 0) red[wv][k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int k = threadIdx.x;
+            P.loss_part[blockIdx.x * 8 + k] =
+                k < 6 ? ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k] : 0.f;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < P.n_opt; ++k) {
+            if (!((P.tick_mask >> k) & 1u)) continue;
+            P.steps[k] = P.steps[k] + 1.f;
+            const double p1 = P.beta_pows[2 * k] * P.beta1, p2 = P.beta_pows[2 * k + 1] * P.beta2;
+            P.beta_pows[2 * k] = p1;
+            P.beta_pows[2 * k + 1] = p2;
+            P.consts[2 * k] = (float)(P.lr / (1.0 - p1));
+            P.consts[2 * k + 1] = (float)sqrt(1.0 - p2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(LB) void k_polyak(float *target, const float *p, long long n,
+                                               float tau, float om_tau) {
+    const long long i4 = ((long long)blockIdx.x * LB + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        float t[4], x[4];
+        ldv<4>(t, target + i4);
+        ldv<4>(x, p + i4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = t[k] * om_tau + x[k] * tau;
+        stv<4>(target + i4, t);
+    } else {
+        for (long long i = i4; i < n; ++i) target[i] = target[i] * om_tau + p[i] * tau;
+    }
+}
+
 // ------------------------------------------------------------------------
 // thin backward / ReLU backward with column partials
 // ------------------------------------------------------------------------
@@ -504,6 +574,7 @@ struct HeadBwd {
     const float *pi; int64_t ld_pi;
     const float *eps, *ls_raw, *log_alpha; float alpha_const;
     float *d_head;
+    int head;                         // TTL_HEAD_SAC or TTL_HEAD_TANH
 };
 
 template <int NA, int V>
@@ -559,6 +630,12 @@ __global__ __launch_bounds__(LB) void k_sac_actor_head_backward(HeadBwd P) {
     const int r = threadIdx.x / NA, i = threadIdx.x - r * NA, m = m0 + r;
     if (m >= P.n_rows) return;
     const float dpi = ((part[0][r][i] + part[1][r][i]) + part[2][r][i]) + part[3][r][i];
+    if (P.head == TTL_HEAD_TANH) {
+        // deterministic actor (offpolicy.py:54-60): d tanh(u) / du = 1 - pi^2
+        const float t = P.pi[(int64_t)m * P.ld_pi + i];
+        P.d_head[(int64_t)m * NA + i] = dpi * (1.f - t * t);
+        return;
+    }
     const float alpha = P.log_alpha ? expf(P.log_alpha[0]) : P.alpha_const;
     const float an = alpha / (float)P.n_rows;
     const float t = P.pi[(int64_t)m * P.ld_pi + i];
@@ -886,15 +963,18 @@ int ttl_colsum_finalize(const ttl_colsum_seg *segs, int32_t n_segs, void *hip_st
 
 int ttl_sac_actor_head_backward(const float *dh, int64_t ld_dh, const float *h, int64_t ld_h,
                                 const float *wa, int32_t n_rows, int32_t n_cols, int32_t n_act,
-                                const float *pi, int64_t ld_pi, const float *eps,
+                                int32_t head, const float *pi, int64_t ld_pi, const float *eps,
                                 const float *log_std_raw, const float *log_alpha,
                                 float alpha_const, float *d_head, void *hip_stream) {
-    if (!dh || !h || !wa || !pi || !eps || !log_std_raw || !d_head || n_rows <= 0 || n_cols <= 0)
+    if (head != TTL_HEAD_SAC && head != TTL_HEAD_TANH)
+        return fail(TTL_ERR_INVALID, "ttl_sac_actor_head_backward: unknown head %d", head);
+    if (!dh || !h || !wa || !pi || !d_head || n_rows <= 0 || n_cols <= 0 ||
+        (head == TTL_HEAD_SAC && (!eps || !log_std_raw)))
         return fail(TTL_ERR_INVALID, "ttl_sac_actor_head_backward: null pointer or empty shape");
     if (ld_dh < n_cols || ld_h < n_cols || ld_pi < n_act)
         return fail(TTL_ERR_INVALID, "ttl_sac_actor_head_backward: a stride is too small");
     HeadBwd P{dh, ld_dh, h, ld_h, wa, n_rows, n_cols, pi, ld_pi, eps, log_std_raw, log_alpha,
-              alpha_const, d_head};
+              alpha_const, d_head, head};
     const bool vec = n_cols % 4 == 0 && ld_dh % 4 == 0 && ld_h % 4 == 0 && aligned16(dh) &&
                      aligned16(h) && aligned16(wa);
     const dim3 grid((n_rows + FWD_ROWS - 1) / FWD_ROWS), block(LB);
@@ -955,6 +1035,34 @@ int ttl_build_learner_inputs(const float *state, int64_t ld_s, const float *acti
                 w1, ld_w1, w1 ? n_w1_rows : 0, wa, row_blocks};
     k_build_learner_inputs<<<dim3(row_blocks + w_blocks), dim3(LB), 0, S(hip_stream)>>>(P);
     LAUNCH_CHECK("k_build_learner_inputs");
+    return TTL_OK;
+}
+
+int ttl_td3_losses(const float *q_online, const float *q_target, const float *reward,
+                   const float *not_done, int32_t n, int32_t n_q, float gamma, float *dq,
+                   float *loss_part, float *steps, float *adam_consts, double *beta_pows,
+                   int32_t n_opt, uint32_t tick_mask, double lr, double beta1, double beta2,
+                   void *hip_stream) {
+    if (!q_online || !q_target || !reward || !not_done || !dq || n <= 0 || (n_q != 1 && n_q != 2))
+        return fail(TTL_ERR_INVALID, "ttl_td3_losses: null pointer, empty batch or n_q not 1 / 2");
+    if (n_opt < 0 || n_opt > 8 || (n_opt && (!steps || !adam_consts || !beta_pows)))
+        return fail(TTL_ERR_INVALID, "ttl_td3_losses: bad optimizer table");
+    Td3LossArgs P{q_online, q_target, reward, not_done, n, n_q, gamma, dq, loss_part, steps,
+                  adam_consts, beta_pows, n_opt, tick_mask, lr, beta1, beta2};
+    k_td3_losses<<<dim3((n + LB - 1) / LB), dim3(LB), 0, S(hip_stream)>>>(P);
+    LAUNCH_CHECK("k_td3_losses");
+    return TTL_OK;
+}
+
+int ttl_polyak_average(float *target, const float *p, int64_t n, double tau, void *hip_stream) {
+    if (!target || !p || n <= 0)
+        return fail(TTL_ERR_INVALID, "ttl_polyak_average: null pointer or empty arena");
+    if (!aligned16(target) || !aligned16(p))
+        return fail(TTL_ERR_INVALID, "ttl_polyak_average: arenas must be 16-byte aligned");
+    const int64_t threads = (n + 3) / 4;
+    k_polyak<<<dim3((unsigned)((threads + LB - 1) / LB)), dim3(LB), 0, S(hip_stream)>>>(
+        target, p, (long long)n, (float)tau, (float)(1.0 - tau));
+    LAUNCH_CHECK("k_polyak");
     return TTL_OK;
 }
 
