@@ -28,6 +28,8 @@
 //
 // Arithmetic as under torch.autocast(fp16): fp16 operands, fp32 accumulation, Linear outputs
 // rounded to fp16, softmax and LayerNorm in fp32.
+#include <cstdlib>
+
 #include "ttl_internal.h"
 #include "ttl_learner.h"
 
@@ -37,6 +39,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 
 constexpr int NT = 4;            // token tiles of 32 (128 tokens)
+// batches of at most this many streamlines take the workgroup-per-streamline kernel
+constexpr long long TTL_ORACLE_NET_WG_MAX_ROWS = 1 << 30;
 constexpr float LN_EPS = 1e-5f;
 
 struct NetArgs {
@@ -353,6 +357,268 @@ __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
     }
 }
 
+// ------------------------------------------------------------------------
+// The same network with one WORKGROUP per streamline: each of its four waves
+// owns one 32-token tile (16 accumulator registers of h^T instead of 64), the
+// keys and values of all tiles meet in LDS once per layer (16 KB), everything
+// else stays wave-private.  A quarter of the dependent work per wave: the
+// latency of one streamline drops ~3x, and at <= 256 registers two workgroups
+// share a CU, so one wave's conversions and softmax run under another's MFMAs.
+// In the last layer only wave 0 (the tile of token 0) goes on after K / V.
+// ------------------------------------------------------------------------
+template <int NHEAD>
+__device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
+                                                  const h8 (*kv)[NT][2][64], const NetArgs &P,
+                                                  int layer, int lane, int n, int hi) {
+    constexpr int DH = 32 / NHEAD;
+    const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
+    const float *WF = P.wf + (long long)layer * P.wf_stride;
+    const h8 *Wo = WH + 6 * 64;
+    const h8 *W1 = WH + 8 * 64;
+    const h8 *W2 = W1 + (long long)P.ff_chunks * 2 * 64;
+    const float *bo = WF + 96;
+    const float *g1 = WF + 128, *be1 = WF + 160;
+    const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
+    const float *b1 = WF + 288;
+
+    h8 KA[NT][2], VA[NT][2];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            KA[mt][s] = kv[0][mt][s][lane];
+            VA[mt][s] = kv[1][mt][s][lane];
+        }
+    const float scale = 1.4426950408889634f / sqrtf((float)DH);     // log2(e) / sqrt(dh)
+    f16x OT = zero16();
+#pragma unroll
+    for (int h = 0; h < NHEAD; ++h) {
+        f16x S[NT];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            if constexpr (NHEAD == 1) {
+                S[mt] = mfma(KA[mt][1], QB[1], mfma(KA[mt][0], QB[0], zero16()));
+            } else if constexpr (NHEAD == 2) {
+                S[mt] = mfma(KA[mt][h], QB[h], zero16());
+            } else {
+                h8 qm = QB[h >> 1];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if ((j >> 2) != (h & 1)) qm[j] = (_Float16)0.f;
+                S[mt] = mfma(KA[mt][h >> 1], qm, zero16());
+            }
+        }
+        float m = S[0][0];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int a = 0; a < 16; ++a) m = fmaxf(m, S[mt][a]);
+        m = fmaxf(m, swap_halves(m));
+        float l = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const float p = __builtin_amdgcn_exp2f((S[mt][a] - m) * scale);
+                S[mt][a] = p;
+                l += p;
+            }
+        l += swap_halves(l);
+        const float inv = 1.f / l;
+        const bool mine = (n / DH) == h;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            h8 PB[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) PB[s][j] = (_Float16)(S[mt][8 * s + j] * inv);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                h8 va = VA[mt][s];
+                if constexpr (NHEAD > 1) {
+                    if (!mine) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) va[j] = (_Float16)0.f;
+                    }
+                }
+                OT = mfma(va, PB[s], OT);
+            }
+        }
+    }
+    h8 OB[2];
+    to_frags(OT, OB);
+    f16x o = mfma(Wo[64 + lane], OB[1], mfma(Wo[lane], OB[0], zero16()));
+    add_rows(o, bo, hi);
+    round_fp16(o);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) hT[a] += o[a];
+    layer_norm(hT, g1, be1, hi);
+
+    // feed-forward on this tile, two 32-unit chunks side by side (two independent
+    // MFMA chains in the wave; the partner workgroup fills what is left)
+    h8 fB[2];
+    to_frags(hT, fB);
+    f16x D2 = zero16();
+    const int pairs = P.ff_chunks >> 1;
+    h8 wA[4], wB[4];
+    float biasA[16], biasB[16];
+    auto load = [&](int c, h8 (&w)[4], float (&bias)[16]) {
+        w[0] = W1[(long long)c * 128 + lane];
+        w[1] = W1[(long long)c * 128 + 64 + lane];
+        w[2] = W2[(long long)c * 128 + lane];
+        w[3] = W2[(long long)c * 128 + 64 + lane];
+        const float *q = b1 + (long long)c * 32 + hi * 16;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) bias[a] = q[a];
+    };
+    load(0, wA, biasA);
+    load(P.ff_chunks > 1 ? 1 : 0, wB, biasB);
+    for (int cp = 0; cp < pairs; ++cp) {
+        h8 nA[4], nB[4];
+        float nbA[16], nbB[16];
+        const int c2 = cp + 1 < pairs ? 2 * cp + 2 : 2 * cp;
+        load(c2, nA, nbA);
+        load(c2 + 1, nB, nbB);
+        f16x da, db;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            da[a] = biasA[a];
+            db[a] = biasB[a];
+        }
+        da = mfma(wA[0], fB[0], da);
+        db = mfma(wB[0], fB[0], db);
+        da = mfma(wA[1], fB[1], da);
+        db = mfma(wB[1], fB[1], db);
+        h8 FA[2], FB2[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 u = (_Float16)da[8 * s + j], v = (_Float16)db[8 * s + j];
+                FA[s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
+                FB2[s][j] = v > (_Float16)0.f ? v : (_Float16)0.f;
+            }
+        D2 = mfma(wA[2], FA[0], D2);
+        D2 = mfma(wA[3], FA[1], D2);
+        D2 = mfma(wB[2], FB2[0], D2);
+        D2 = mfma(wB[3], FB2[1], D2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wA[k] = nA[k];
+            wB[k] = nB[k];
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            biasA[a] = nbA[a];
+            biasB[a] = nbB[a];
+        }
+    }
+    if (P.ff_chunks & 1) {                      // an odd last chunk
+        const int c = P.ff_chunks - 1;
+        h8 w[4];
+        float bias[16];
+        load(c, w, bias);
+        f16x d1;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) d1[a] = bias[a];
+        d1 = mfma(w[1], fB[1], mfma(w[0], fB[0], d1));
+        h8 F[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 u = (_Float16)d1[8 * s + j];
+                F[s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
+            }
+        D2 = mfma(w[3], F[1], mfma(w[2], F[0], D2));
+    }
+    add_rows(D2, b2, hi);
+    round_fp16(D2);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) hT[a] += D2[a];
+    layer_norm(hT, g2, be2, hi);
+}
+
+template <int NHEAD>
+__global__ __launch_bounds__(256, 2) void k_oracle_net_wg(NetArgs P) {
+    __shared__ h8 kv[2][NT][2][64];                 // keys | values: [tile][k-step][lane], 16 KB
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // wave w owns token tile w
+    const long long row = blockIdx.x;               // one workgroup per streamline
+    const int n = lane & 31, hi = lane >> 5;
+    const float *dirs = P.dirs + row * (127 * 3);
+
+    f16x hT;
+    {
+        const float *E = P.embed + hi * 64;
+        const int t = 32 * w + n;
+        float x0, x1, x2;
+        if (t == 0) {
+            x0 = P.cls[0]; x1 = P.cls[1]; x2 = P.cls[2];
+        } else {
+            const float *d = dirs + (t - 1) * 3;
+            x0 = d[0]; x1 = d[1]; x2 = d[2];
+        }
+        x0 = (float)(_Float16)x0; x1 = (float)(_Float16)x1; x2 = (float)(_Float16)x2;
+        const float *pe = P.pe + ((long long)w * 64 + lane) * 16;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            float e = E[4 * a + 0] * x0 + E[4 * a + 1] * x1 + E[4 * a + 2] * x2 + E[4 * a + 3];
+            e = (float)(_Float16)e;
+            e = e > 0.f ? e : 0.f;
+            e = (float)(_Float16)(e * (float)(_Float16)5.656854249492381f);
+            hT[a] = e + pe[a];
+        }
+    }
+
+    for (int layer = 0; layer < P.n_layers; ++layer) {
+        const bool last = layer == P.n_layers - 1;
+        const bool goes_on = !last || w == 0;       // the last layer only feeds token 0's tile
+        const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
+        const float *WF = P.wf + (long long)layer * P.wf_stride;
+        const h8 *Wqk = WH, *Wv = WH + 4 * 64;
+        const float *bqk = WF, *bv = WF + 64;
+        h8 hB[2], QB[2];
+        to_frags(hT, hB);
+        {
+            f16x k = mfma(Wqk[3 * 64 + lane], hB[1], mfma(Wqk[2 * 64 + lane], hB[0], zero16()));
+            add_rows(k, bqk + 32, hi);
+            h8 f[2];
+            to_frags(k, f);
+            kv[0][w][0][lane] = f[0];
+            kv[0][w][1][lane] = f[1];
+            f16x v = mfma(hB[1], Wv[64 + lane], mfma(hB[0], Wv[lane], zero16()));
+            const float bvc = bv[n];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] += bvc;
+            to_frags(v, f);
+            kv[1][w][0][lane] = f[0];
+            kv[1][w][1][lane] = f[1];
+        }
+        if (goes_on) {
+            f16x q = mfma(Wqk[64 + lane], hB[1], mfma(Wqk[lane], hB[0], zero16()));
+            add_rows(q, bqk, hi);
+            to_frags(q, QB);
+        }
+        __syncthreads();
+        if (goes_on) attention_ff_tile<NHEAD>(hT, QB, kv, P, layer, lane, n, hi);
+        __syncthreads();                            // kv is rewritten by the next layer
+    }
+
+    if (w == 0) {
+        float dot = 0.f;
+        const float *wh = P.head + hi * 16;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) dot += (float)(_Float16)hT[a] * (float)(_Float16)wh[a];
+        dot += swap_halves(dot);
+        if (lane == 0) {
+            float y = (float)(_Float16)(dot + (float)(_Float16)P.head[32]);
+            y = 1.f / (1.f + expf(-y));
+            P.out[row] = (float)(_Float16)y;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -374,11 +640,25 @@ int ttl_oracle_net_forward(const float *dirs, int64_t n, const void *packed_half
     NetArgs P{dirs, (long long)n, reinterpret_cast<const _Float16 *>(packed_half), packed_float,
               embed, cls, pos_enc, head, n_layers, chunks,
               (long long)(8 + 4 * chunks) * 64, (long long)288 + 32 * chunks, scores};
-    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-    if (n_head == 1) k_oracle_net<1><<<grid, block, 0, s>>>(P);
-    else if (n_head == 2) k_oracle_net<2><<<grid, block, 0, s>>>(P);
-    else k_oracle_net<4><<<grid, block, 0, s>>>(P);
+    // one workgroup per streamline (a quarter of the latency; TTL_ORACLE_NET_WG = 1 always,
+    // 0 never) or one wavefront per streamline
+    static const int wg_mode = [] {
+        const char *v = getenv("TTL_ORACLE_NET_WG");
+        return v ? atoi(v) : -1;
+    }();
+    const bool wg = wg_mode == 1 || (wg_mode != 0 && n <= TTL_ORACLE_NET_WG_MAX_ROWS);
+    if (wg) {
+        const dim3 grid((unsigned)n), block(256);
+        if (n_head == 1) k_oracle_net_wg<1><<<grid, block, 0, s>>>(P);
+        else if (n_head == 2) k_oracle_net_wg<2><<<grid, block, 0, s>>>(P);
+        else k_oracle_net_wg<4><<<grid, block, 0, s>>>(P);
+    } else {
+        const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+        if (n_head == 1) k_oracle_net<1><<<grid, block, 0, s>>>(P);
+        else if (n_head == 2) k_oracle_net<2><<<grid, block, 0, s>>>(P);
+        else k_oracle_net<4><<<grid, block, 0, s>>>(P);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(TTL_ERR_HIP, "k_oracle_net: %s", hipGetErrorString(e));
