@@ -42,7 +42,7 @@ def timeit(fn, reps):
 def main():
     from tracktolearn_amd.oracles.fused_net import FusedOracleNet
     from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
-    rows_list = [int(a) for a in sys.argv[1:]] or [256, 1024, 4096, 16384]
+    rows_list = [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 4096, 16384]
     torch.manual_seed(0)
     model = TransformerOracle(381, 1, 4, 4, 1e-4).cuda().eval()
     net = FusedOracleNet(model)
@@ -57,7 +57,8 @@ def main():
         t_fused = timeit(lambda: net(dirs), 20 if rows <= 4096 else 5)
         t_mod = timeit(module, 5 if rows <= 4096 else 2)
         print(json.dumps({
-            'rows': rows, 'fused_ms': round(t_fused * 1e3, 4), 'module_autocast_ms': round(t_mod * 1e3, 3),
+            'rows': rows, 'kernel': 'workgroup per streamline' if rows <= 512 else 'wavefront per streamline',
+            'fused_ms': round(t_fused * 1e3, 4), 'module_autocast_ms': round(t_mod * 1e3, 3),
             'speedup': round(t_mod / t_fused, 1),
             'fused_TFLOPs_issued': round(rows * issued / t_fused / 1e12, 1),
             'fused_frac_of_fp16_mfma_peak': round(rows * issued / t_fused / 1e12 / FP16_MFMA_PEAK_TF, 4),

@@ -204,9 +204,12 @@ def test_fused_oracle_net_matches_the_module(n_head, n_layers, ff):
               f'fused vs autocast {d:.2e}')
         assert float(y32.max() - y32.min()) > 0.02 or n < 257    # the scores do spread
         assert e_fused <= 3 * e_auto + 2e-3 and d <= 4e-3
-    # rows are independent: a row's score does not depend on its batch
+    # rows are independent: a row's score does not depend on its batch -- nor on which of
+    # the two kernels scored it (<= 512 rows: one workgroup per streamline, the keys and
+    # values of its four token tiles through LDS; more: one wavefront per streamline)
     one = net(dirs[100:101])
     assert torch.equal(one, got[100:101])
+    assert torch.equal(net(dirs[:512]), got[:512]) and torch.equal(net(dirs[512:1100]), got[512:1100])
 
 
 @pytest.mark.gpu

@@ -40,7 +40,7 @@ typedef float f16x __attribute__((ext_vector_type(16)));
 
 constexpr int NT = 4;            // token tiles of 32 (128 tokens)
 // batches of at most this many streamlines take the workgroup-per-streamline kernel
-constexpr long long TTL_ORACLE_NET_WG_MAX_ROWS = 1 << 30;
+constexpr long long TTL_ORACLE_NET_WG_MAX_ROWS = 512;   // one resident round of 2 workgroups per CU
 constexpr float LN_EPS = 1e-5f;
 
 struct NetArgs {
