@@ -231,6 +231,19 @@ TTL_API int ttl_build_learner_inputs(const float *state, int64_t ld_s, const flo
                                      int64_t ld, const float *w1, int64_t ld_w1,
                                      int32_t n_w1_rows, float *wa, void *hip_stream);
 
+/* OffPolicyReplayBuffer.add (TrackToLearn/algorithms/shared/replay.py:56-92) for a
+ * batch of n transitions already on the device, one launch: transition i goes to
+ * ring slot (ptr + i) mod max_size -- state[i], action[i], next_state[row_dest[i]]
+ * (row_dest: where env.step_device() wrote the state row of active row i; NULL:
+ * row i), reward (float64 as the env returns it, or float32; exactly one array),
+ * not_done = 1 - done (uint8).  The caller advances ptr and size. */
+TTL_API int ttl_replay_add(const float *state, const float *action, const float *next_state,
+                           const int32_t *row_dest, const double *reward_f64,
+                           const float *reward_f32, const uint8_t *done, int32_t n,
+                           int32_t n_state, int32_t n_act, int64_t ptr, int64_t max_size,
+                           float *ring_state, float *ring_action, float *ring_next_state,
+                           float *ring_reward, float *ring_not_done, void *hip_stream);
+
 /* OffPolicyReplayBuffer.sample (TrackToLearn/algorithms/shared/replay.py:94-143:
  * `ind = torch.randperm(size)[:batch]`, five `index_select`s) in one launch:
  * `batch` (<= size) DISTINCT ring rows drawn uniformly and gathered into the

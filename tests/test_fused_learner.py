@@ -483,6 +483,53 @@ def test_fused_sac_losses_dict_matches_autograd():
 
 
 @pytest.mark.gpu
+def test_replay_add_kernel_fills_the_ring_like_the_torch_path(monkeypatch):
+    """`add_partitioned` with what `env.step_device()` hands out (float32 rows,
+    int32 row_dest, float64 reward, uint8 done) is one launch of
+    `ttl_replay_add`; the ring it leaves equals the torch scatter path's, also
+    across the wrap and with float32 rewards / bool dones."""
+    from tracktolearn_amd.algorithms.shared import replay as rp
+    W, A, cap = 41, 3, 1000
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(4)
+    calls = []
+    real = rp.OffPolicyReplayBuffer._add_device
+
+    def spy(self, *a):
+        done = real(self, *a)
+        calls.append(done)
+        return done
+    monkeypatch.setattr(rp.OffPolicyReplayBuffer, '_add_device', spy)
+    fast = rp.OffPolicyReplayBuffer(W, A, max_size=cap, device=dev)
+    slow = rp.OffPolicyReplayBuffer(W, A, max_size=cap, device=dev)
+    for i, n in enumerate((300, 1, 450, 400, 1000, 77)):          # 4th add wraps
+        s, a = torch.randn(n, W, generator=g).to(dev), torch.randn(n, A, generator=g).to(dev)
+        ns = torch.randn(n, W, generator=g).to(dev)
+        dest = torch.randperm(n, generator=g).to(dev)
+        r = torch.rand(n, generator=g, dtype=torch.float64).to(dev)
+        d = (torch.rand(n, generator=g) > 0.5).to(dev)
+        ns_part = torch.empty_like(ns)
+        ns_part[dest] = ns
+        if i % 2:
+            r_in, d_in = r.float(), d
+        else:
+            r_in, d_in = r, d.to(torch.uint8)
+        fast.add_partitioned(s, a, ns_part, dest.int(), r_in, d_in)
+        slow.add(s, a, ns, r_in, d_in)
+        assert fast.ptr == slow.ptr and fast.size == slow.size
+        for name in ('state', 'action', 'next_state', 'reward', 'not_done'):
+            assert torch.equal(getattr(fast, name), getattr(slow, name)), (i, name)
+    assert calls == [True] * 6
+    # int64 row_dest (not what the env returns) keeps the torch path, same ring
+    fast.add_partitioned(s, a, ns_part, dest, r, d)
+    slow.add(s, a, ns, r, d)
+    assert calls[-1] is False and torch.equal(fast.next_state, slow.next_state)
+    # more rows than the ring holds cannot be one launch
+    big = rp.OffPolicyReplayBuffer(W, A, max_size=50, device=dev)
+    assert not real(big, s, a, ns_part, dest.int(), r, d.to(torch.uint8))
+
+
+@pytest.mark.gpu
 def test_replay_sample_kernel_draws_distinct_uniform_rows():
     """`OffPolicyReplayBuffer.sample` on the GPU (`ttl_replay_sample`): what
     `randperm(size)[:batch]` + five `index_select`s give -- distinct ring rows,

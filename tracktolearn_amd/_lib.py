@@ -188,6 +188,10 @@ SYMBOLS = {
                                            C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    'ttl_replay_add': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttl_replay_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                     C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -69,6 +69,10 @@ class OffPolicyReplayBuffer(object):
         ``i``.  The rows are scattered straight into the ring slots of their
         transitions, no intermediate re-ordering copy."""
         n = len(state)
+        if n == 0:
+            return
+        if self._add_device(state, action, next_state, row_dest, reward, done):
+            return
         ind = self._slots(n)
         self._put(self.state, ind, self._dev(state))
         self._put(self.action, ind, self._dev(action))
@@ -104,6 +108,43 @@ class OffPolicyReplayBuffer(object):
                 self.reward.index_select(0, ind).squeeze(-1),
                 self.not_done.index_select(0, ind).squeeze(-1))
 
+    def _add_device(self, state, action, next_state, row_dest, reward, done):
+        """``add_partitioned`` as one launch of ``ttl_replay_add`` when everything
+        already sits on the ring's GPU in the dtypes the env hands out (float32
+        rows, int32 ``row_dest``, float64 or float32 reward, uint8 ``done``);
+        False: the caller takes the torch path."""
+        def ok(t, dtypes):
+            return isinstance(t, torch.Tensor) and t.device == self.device and t.dtype in dtypes \
+                and t.is_contiguous()
+        n = len(state)
+        if self.device.type != 'cuda' or n > self.max_size or len(action) != n or \
+                state.shape[1:] != self.state.shape[1:] or \
+                action.shape[1:] != self.action.shape[1:] or \
+                next_state.shape[1:] != self.state.shape[1:] or row_dest.numel() != n or \
+                os.environ.get('TTL_REPLAY_RANDPERM', '0') == '1' or \
+                not (ok(state, (torch.float32,)) and ok(action, (torch.float32,)) and
+                     ok(next_state, (torch.float32,)) and ok(row_dest, (torch.int32,)) and
+                     ok(reward, (torch.float64, torch.float32)) and
+                     ok(done, (torch.uint8, torch.bool))) or \
+                reward.numel() != n or done.numel() != n or next_state.shape[0] != n:
+            return False
+        import ctypes as C
+
+        from tracktolearn_amd import _lib
+        lib = _lib.load()
+        r64 = reward.data_ptr() if reward.dtype == torch.float64 else None
+        r32 = reward.data_ptr() if reward.dtype == torch.float32 else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.ttl_replay_add(
+                state.data_ptr(), action.data_ptr(), next_state.data_ptr(), row_dest.data_ptr(),
+                r64, r32, done.data_ptr(), n, self.state.shape[1], self.action.shape[1],
+                self.ptr, self.max_size, self.state.data_ptr(), self.action.data_ptr(),
+                self.next_state.data_ptr(), self.reward.data_ptr(), self.not_done.data_ptr(),
+                stream), 'ttl_replay_add')
+        self._advance(n)
+        return True
+
     def _sample_device(self, n):
         import ctypes as C
 
@@ -116,11 +157,12 @@ class OffPolicyReplayBuffer(object):
         a, r, d = torch.empty((n, A), **z), torch.empty(n, **z), torch.empty(n, **z)
         self.last_indices = torch.empty(n, dtype=torch.int64, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(lib.ttl_replay_sample(
-            self.state.data_ptr(), self.action.data_ptr(), self.next_state.data_ptr(),
-            self.reward.data_ptr(), self.not_done.data_ptr(), self.size, W, A, n,
-            key[0], key[1], s.data_ptr(), a.data_ptr(), ns.data_ptr(), r.data_ptr(),
-            d.data_ptr(), self.last_indices.data_ptr(), stream), 'ttl_replay_sample')
+        with torch.cuda.device(self.device):
+            _lib.check(lib.ttl_replay_sample(
+                self.state.data_ptr(), self.action.data_ptr(), self.next_state.data_ptr(),
+                self.reward.data_ptr(), self.not_done.data_ptr(), self.size, W, A, n,
+                key[0], key[1], s.data_ptr(), a.data_ptr(), ns.data_ptr(), r.data_ptr(),
+                d.data_ptr(), self.last_indices.data_ptr(), stream), 'ttl_replay_sample')
         return s, a, ns, r, d
 
     def clear_memory(self):

@@ -802,6 +802,39 @@ __global__ __launch_bounds__(LB) void k_replay_sample(SampleArgs P) {
     }
 }
 
+// ------------------------------------------------------------------------
+// replay ring: append a batch of transitions in one launch
+// ------------------------------------------------------------------------
+struct AddArgs {
+    const float *state, *action, *next_state;
+    const int *row_dest;            // next_state row of transition i, or null (= i)
+    const double *reward64; const float *reward32;
+    const unsigned char *done;
+    int n, n_state, n_act;
+    long long ptr, max_size;
+    float *r_state, *r_action, *r_next, *r_reward, *r_not_done;
+};
+
+__global__ __launch_bounds__(LB) void k_replay_add(AddArgs P) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * NW + wv;              // one wave per transition
+    if (i >= P.n) return;
+    const long long slot = (P.ptr + i) % P.max_size;
+    const long long src_next = P.row_dest ? P.row_dest[i] : i;
+    const float *s = P.state + (long long)i * P.n_state;
+    const float *s2 = P.next_state + src_next * P.n_state;
+    float *ds = P.r_state + slot * P.n_state, *dn = P.r_next + slot * P.n_state;
+    for (int c = lane; c < P.n_state; c += 64) {
+        ds[c] = s[c];
+        dn[c] = s2[c];
+    }
+    if (lane < P.n_act) P.r_action[slot * P.n_act + lane] = P.action[(long long)i * P.n_act + lane];
+    if (lane == 0) {
+        P.r_reward[slot] = P.reward64 ? (float)P.reward64[i] : P.reward32[i];
+        P.r_not_done[slot] = 1.f - (float)P.done[i];
+    }
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -1063,6 +1096,26 @@ int ttl_polyak_average(float *target, const float *p, int64_t n, double tau, voi
     k_polyak<<<dim3((unsigned)((threads + LB - 1) / LB)), dim3(LB), 0, S(hip_stream)>>>(
         target, p, (long long)n, (float)tau, (float)(1.0 - tau));
     LAUNCH_CHECK("k_polyak");
+    return TTL_OK;
+}
+
+int ttl_replay_add(const float *state, const float *action, const float *next_state,
+                   const int32_t *row_dest, const double *reward_f64, const float *reward_f32,
+                   const uint8_t *done, int32_t n, int32_t n_state, int32_t n_act, int64_t ptr,
+                   int64_t max_size, float *ring_state, float *ring_action,
+                   float *ring_next_state, float *ring_reward, float *ring_not_done,
+                   void *hip_stream) {
+    if (!state || !action || !next_state || !done || (!reward_f64 == !reward_f32) || !ring_state ||
+        !ring_action || !ring_next_state || !ring_reward || !ring_not_done)
+        return fail(TTL_ERR_INVALID, "ttl_replay_add: null pointer (exactly one reward array)");
+    if (n <= 0 || n > max_size || ptr < 0 || ptr >= max_size || n_state <= 0 || n_act <= 0 ||
+        n_act > 64)
+        return fail(TTL_ERR_INVALID, "ttl_replay_add: need 0 < n <= max_size and 0 <= ptr < max_size");
+    AddArgs P{state, action, next_state, row_dest, reward_f64, reward_f32, done, n, n_state, n_act,
+              (long long)ptr, (long long)max_size, ring_state, ring_action, ring_next_state,
+              ring_reward, ring_not_done};
+    k_replay_add<<<dim3((n + NW - 1) / NW), dim3(LB), 0, S(hip_stream)>>>(P);
+    LAUNCH_CHECK("k_replay_add");
     return TTL_OK;
 }
 
