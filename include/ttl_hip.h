@@ -41,7 +41,7 @@ extern "C" {
 #define TTL_API
 #endif
 
-#define TTL_ABI_VERSION 10
+#define TTL_ABI_VERSION 11
 
 #define TTL_OK 0
 #define TTL_ERR_INVALID (-1) /* bad argument / shape / alignment             */
@@ -256,6 +256,15 @@ TTL_API int ttl_env_step_end(ttl_env *env, const uint8_t *extra_flags, int32_t o
  * the next ttl_env_step() is then refused unless n_active equals it. */
 TTL_API int ttl_env_wait_counts(ttl_env *env);
 
+/* Between a step that was given host_counts and its harvest: waits for the
+ * counts like ttl_env_wait_counts() (without consuming them) and returns the
+ * rows that stopped in that step, compacted in active-row order -- what
+ * OracleReward scores (oracle_reward.py:78-90: idx = arange(N)[dones]):
+ * stop_list[2 q] = active row, stop_list[2 q + 1] = streamline id (row of the
+ * history buffer) of the q-th of them, q < *n_stopped.  Device memory owned by
+ * the handle, rewritten by the next step. */
+TTL_API int ttl_env_stopped(ttl_env *env, const int32_t **stop_list, int32_t *n_stopped);
+
 /* TrackingEnvironment.harvest (tracking_env.py:223-245): lengths of the
  * streamlines that stopped in the last step, continue_idx <- survivors
  * (stable).  If the last step used ORDER_ACTIVE and state_out != NULL the
@@ -421,6 +430,26 @@ TTL_API int ttl_resample_streamlines(const float *points, int64_t row_pitch,
                              const int32_t *lengths32, const int64_t *lengths64,
                              int32_t n, int32_t max_len, int32_t nb_points, float *out,
                              void *hip_stream);
+
+/* The env's oracle path in one launch (oracle_reward.py:78-90,
+ * stopping_criteria.py:132-150 -> oracles/oracle.py:52-72): for streamline
+ * ids[r * id_stride] (NULL: r) of the history buffer, r < n, take its first
+ * n_points points, map them with the row-major 3x3 matrix lin (host memory,
+ * p' = p @ lin; NULL: none), resample to nb_points along the arc length as
+ * ttl_resample_streamlines() does, and write the nb_points - 1 segment vectors:
+ * dirs_out [n][nb_points - 1][3] float32, the network's input. */
+TTL_API int ttl_oracle_segments(const float *history, int64_t row_pitch, const int32_t *ids,
+                                int32_t id_stride, int32_t n, int32_t n_points,
+                                const float *lin, int32_t nb_points, float *dirs_out,
+                                void *hip_stream);
+
+/* OracleReward's sparse bonus (oracle_reward.py:84-93) for the rows of
+ * ttl_env_stopped(): term[0 .. n_active) = 0, then term[row_q] = bonus where
+ * scores[q] > 0.5 (q < n_scored <= n_stopped; the rest was not scored), and
+ * reward[row_q] += term[row_q]. */
+TTL_API int ttl_oracle_bonus(const float *scores, int32_t n_scored, const int32_t *stop_list,
+                             int32_t n_stopped, double bonus, int32_t n_active, double *term,
+                             double *reward, void *hip_stream);
 
 /* Ragged pack of tracked streamlines (ABI v8), the device side of
  * TrackingEnvironment.get_streamlines (tracking_env.py:263-284) and of the

@@ -650,6 +650,57 @@ def test_counts_into_pageable_host_memory_fall_back_to_the_copy():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('N,tail_fused', [(3000, '1'), (40000, '1'), (40000, '0')],
+                         ids=['one_launch_tail', 'k_tail', 'k_prefix'])
+def test_stopped_rows_list(N, tail_fused, monkeypatch):
+    """ttl_env_stopped: between a step and its harvest, the {active row,
+    streamline id} pairs of the rows that stopped, in row order -- what
+    `np.arange(N)[dones]` and `continue_idx[dones]` give (oracle_reward.py:78)
+    -- from each of the three kernels that compact a step."""
+    import ctypes as C
+
+    from tracktolearn_amd import _lib
+    from tracktolearn_amd.environments import TrackingEnvironment
+    monkeypatch.setenv('TTL_TAIL_FUSED', tail_fused)
+    if tail_fused == '0':       # the Python mirror of the knob is read at import
+        monkeypatch.setattr(TrackingEnvironment, 'TAIL_FUSED_MAX_ROWS', 0)
+    monkeypatch.setattr(TrackingEnvironment, 'SPATIAL_ORDER_MIN', 1)
+    monkeypatch.setattr(TrackingEnvironment, 'SPATIAL_ORDER_REFRESH', 3)
+    D = 20
+    sh, mask, pk = synthetic_subject(D)
+    rng = np.random.RandomState(11)
+    vox = np.argwhere(mask)
+    seeds = vox[rng.randint(0, len(vox), N)] + rng.uniform(-0.5, 0.5, (N, 3))
+    env = _hip_env(D, noisy=False, affine_dtype=np.float32, seeds=seeds, n_dirs=4,
+                   max_length=25.0, reward=False)
+    lib = _lib.load()
+    lst, n_stop = C.c_void_p(), C.c_int32()
+    state = env.reset(0, N)
+    assert lib.ttl_env_stopped(env._handle, C.byref(lst), C.byref(n_stop)) == _lib.ERR_STATE
+    step, seen = 0, 0
+    while env._n_active:
+        n = env._n_active
+        idx = env.continue_idx.copy()
+        _, _, done, _ = env.step_device(env.scripted_actions(state, step, 9, 0.25))
+        _lib.check(lib.ttl_env_stopped(env._handle, C.byref(lst), C.byref(n_stop)), 'stopped')
+        d = done.cpu().numpy().astype(bool)
+        assert n_stop.value == int(d.sum())
+        if n_stop.value:
+            # the list lives in the workspace the env handed to the library
+            off = lst.value - env._buf_ws.data_ptr()
+            got = env._buf_ws[off:off + 8 * n_stop.value].view(torch.int32).cpu().numpy() \
+                .reshape(-1, 2)
+            assert np.array_equal(got[:, 0], np.nonzero(d)[0])
+            assert np.array_equal(got[:, 1], idx[d])
+            seen += n_stop.value
+        # asking twice is harmless, and the harvest still finds its counts
+        _lib.check(lib.ttl_env_stopped(env._handle, C.byref(lst), C.byref(n_stop)), 'stopped')
+        state, _ = env.harvest()
+        assert lib.ttl_env_stopped(env._handle, C.byref(lst), C.byref(n_stop)) == _lib.ERR_STATE
+        step += 1
+    assert seen == N
+
+
 def test_episode_on_a_non_default_stream():
     """Everything is ordered on the caller's stream (torch's current stream):
     a whole device-resident episode of 20 000 streamlines issued inside a

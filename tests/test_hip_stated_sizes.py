@@ -321,7 +321,8 @@ def test_config3_update_on_gpu_matches_cpu(config3_run):
 # --------------------------------------------------------------------------
 # config 5 (one GPU's shard)
 # --------------------------------------------------------------------------
-def test_config5_shard_oracle_bonus_and_stopping(tmp_path):
+@pytest.mark.parametrize('fast', [True, False], ids=['library_calls', 'torch_ops'])
+def test_config5_shard_oracle_bonus_and_stopping(tmp_path, monkeypatch, fast):
     """16 384 streamlines on 96^3, reward on, oracle_bonus 10, oracle batches
     of 4 096 (the default): the sparse bonus on the rows that just stopped and
     the ORACLE stop bit on all active rows, re-derived on the CPU with a
@@ -329,9 +330,12 @@ def test_config5_shard_oracle_bonus_and_stopping(tmp_path):
     paths are live while > 4 096 streamlines are still active (the tail-batch
     quirk needs more than one batch)."""
     from ref_resample import resample_streamlines     # CPU re-derivation
+    from tracktolearn_amd.environments.tracking_env import TrackingEnvironment
     from tracktolearn_amd.oracles.oracle import OracleSingleton
     from tracktolearn_amd.oracles.transformer_oracle import (
         TransformerOracle, save_random_checkpoint)
+    # the oracle path as four library calls (default) / as torch ops
+    monkeypatch.setattr(TrackingEnvironment, 'oracle_fast', fast)
     N, K, BS = 16384, 4, 4096
     ck = save_random_checkpoint(str(tmp_path / 'o.ckpt'), n_head=4, n_layers=4,
                                 seed=5)
@@ -441,6 +445,66 @@ def test_config5_shard_oracle_bonus_and_stopping(tmp_path):
             break
     assert saw_bonus and saw_oracle_stop and saw_oracle_keep and saw_tail
     OracleSingleton.reset()
+
+
+def test_oracle_path_as_library_calls_equals_the_torch_ops(tmp_path, monkeypatch):
+    """The same episode twice -- oracle stopping + bonus through
+    `ttl_env_stopped` / `ttl_oracle_segments` / `ttl_oracle_bonus`, and through
+    the torch ops they replace (`nonzero`, index gathers, matmul, resample,
+    difference, `index_put`): dones, flags, rewards, oracle terms and the
+    tractogram are identical, batches of 1 024 so that the dropped-tail quirk
+    is live in both.  (A reference anatomy on another grid -- the 3x3 map in
+    front of the resampler -- is covered at the kernel:
+    tests/test_oracle_net.py::test_oracle_segments_kernel.)"""
+    from tracktolearn_amd.environments.tracking_env import TrackingEnvironment
+    from tracktolearn_amd.oracles.oracle import OracleSingleton
+    from tracktolearn_amd.oracles.transformer_oracle import save_random_checkpoint
+    ck = save_random_checkpoint(str(tmp_path / 'o.ckpt'), n_head=4, n_layers=2, seed=3)
+    runs = {}
+    for fast in (True, False):
+        monkeypatch.setattr(TrackingEnvironment, 'oracle_fast', fast)
+        OracleSingleton.reset()
+        env, _ = _env(32, 3000, 4, reward=True, min_length=1.5, max_length=60.0, seed=6,
+                      dto_extra=dict(oracle_bonus=7.0, oracle_checkpoint=ck,
+                                     oracle_stopping_criterion=True, theta=60.0))
+        env._oracle.batch_size = 1024
+        scored = []
+        real = env._oracle.net.__class__.__call__
+
+        def spy(self_, dirs, _real=real, _scored=scored):
+            out = _real(self_, dirs)
+            _scored.append((dirs.clone(), out.clone()))
+            return out
+        monkeypatch.setattr(env._oracle.net.__class__, '__call__', spy)
+        state = env.reset(0, 3000)
+        log = []
+        for step in range(40):
+            a = env.scripted_actions(state, step, seed=1, wobble=0.15)
+            _, reward, done, info = env.step(a)
+            term = env._last_oracle_term
+            log.append((reward.copy(), done.copy(),
+                        None if term is None else term.cpu().numpy(),
+                        info['reward_info']['oracle_reward']))
+            state, _ = env.harvest()
+            if env._n_active == 0:
+                break
+        monkeypatch.setattr(env._oracle.net.__class__, '__call__', real)
+        runs[fast] = (log, env.flags.copy(), env.lengths.copy(), scored)
+    OracleSingleton.reset()
+    (la, fa, na, sa), (lb, fb, nb, sb) = runs[True], runs[False]
+    assert len(sa) == len(sb) > 10
+    for (da, oa), (db, ob) in zip(sa, sb):
+        assert torch.equal(da, db) and torch.equal(oa, ob)
+    assert len(la) == len(lb) and (fa & 64).any()
+    assert np.array_equal(fa, fb) and np.array_equal(na, nb)
+    bonus = False
+    for (ra, da, ta, ia), (rb, db, tb, ib) in zip(la, lb):
+        assert np.array_equal(da, db) and np.array_equal(ra, rb) and ia == ib
+        assert (ta is None) == (tb is None)
+        if ta is not None:
+            assert np.array_equal(ta, tb)
+            bonus |= bool((ta == 7.0).any())
+    assert bonus
 
 
 # --------------------------------------------------------------------------

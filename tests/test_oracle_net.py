@@ -228,3 +228,53 @@ def test_reference_transformer_vector_through_the_fused_net():
         pytest.skip('golden vector of another architecture')
     y = FusedOracleNet(model)(torch.from_numpy(z['x']).cuda()).cpu().numpy()
     assert np.abs(y - z['y']).max() <= 5e-3
+
+
+@pytest.mark.gpu
+def test_oracle_segments_kernel():
+    """`ttl_oracle_segments` (history rows -> network input in one launch)
+    against the separate steps it replaces: index gather of the rows' first L
+    points, `@ lin`, `ttl_resample_streamlines`, difference.  Without the 3x3
+    map the result is bit-identical; with it, the map's roundings may differ
+    from the BLAS's by an ulp of a coordinate."""
+    import ctypes as C
+
+    from tracktolearn_amd import _lib
+    from tracktolearn_amd.oracles.oracle import resample_streamlines
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(2)
+    n_hist, max_pts = 700, 267
+    hist = (torch.randn(n_hist, max_pts, 3, generator=g).cumsum(1) * 0.3 + 40).to(dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    m = torch.tensor([[0.9, 0.05, 0.0], [-0.03, 1.1, 0.02], [0.01, 0.0, 0.8]])
+    for n, L, stride in ((1, 2, 1), (5, 3, 2), (300, 11, 1), (700, 128, 1), (257, 267, 2),
+                         (64, 200, 1)):
+        ids = torch.randperm(n_hist, generator=g)[:n].int()
+        pairs = torch.stack([torch.arange(n, dtype=torch.int32), ids], 1).contiguous().to(dev)
+        ids_dev = ids.to(dev)
+        for lin in (None, m):
+            pts = hist[ids_dev.long(), :L]
+            if lin is not None:
+                pts = pts @ lin.to(dev)
+            data = resample_streamlines(pts, torch.full((n,), L, dtype=torch.long, device=dev))
+            want = data[:, 1:] - data[:, :-1]
+            got = torch.empty(n, 127, 3, device=dev)
+            src = pairs.data_ptr() + 4 if stride == 2 else ids_dev.data_ptr()
+            lin_c = None if lin is None else (C.c_float * 9)(*[float(v) for v in lin.ravel()])
+            _lib.check(lib.ttl_oracle_segments(hist.data_ptr(), hist.stride(0), src, stride, n, L,
+                                               lin_c, 128, got.data_ptr(), stream), 'segments')
+            if lin is None:
+                assert torch.equal(got, want), (n, L)
+            else:
+                assert torch.allclose(got, want, rtol=0, atol=2e-5), (n, L)
+    # ids = NULL: the first n rows
+    got = torch.empty(9, 127, 3, device=dev)
+    _lib.check(lib.ttl_oracle_segments(hist.data_ptr(), hist.stride(0), None, 1, 9, 50, None, 128,
+                                       got.data_ptr(), stream), 'segments')
+    data = resample_streamlines(hist[:9, :50], torch.full((9,), 50, dtype=torch.long, device=dev))
+    assert torch.equal(got, data[:, 1:] - data[:, :-1])
+    # refused, not launched
+    assert lib.ttl_oracle_segments(hist.data_ptr(), 3 * 10, None, 1, 9, 50, None, 128,
+                                   got.data_ptr(), stream) == _lib.ERR_INVALID
+

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (keep above the CDLL below)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libttl_hip.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 SH_LINEAR, SH_BRICK4 = 0, 1
 MODE_F32 = 0
 MODE_F64DIR = 1
@@ -109,6 +109,11 @@ SYMBOLS = {
                                    C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p]),
     'ttl_env_wait_counts': (C.c_int, [C.c_void_p]),
+    'ttl_env_stopped': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    'ttl_oracle_segments': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'ttl_oracle_bonus': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
+                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ttl_env_harvest_wait': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.POINTER(C.c_int32)]),
     'ttl_env_harvest': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p,

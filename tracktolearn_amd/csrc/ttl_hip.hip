@@ -560,6 +560,9 @@ __global__ __launch_bounds__(BLOCK) void k_prefix(EnvParams P,
     // of the streamlines that just stopped here (tracking_env.py:236)
     if (stop && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
     P.surv_pos[i] = stop ? -1 : pos;
+    // the rows that stopped, compacted in row order (ttl_env_stopped: the
+    // oracle reward scores exactly these, oracle_reward.py:78-90)
+    if (stop) *reinterpret_cast<int2 *>(P.stop_list + 2 * (size_t)(i - pos)) = int2{i, g};
     int dest = i;
     if (order == TTL_ORDER_PARTITION) dest = stop ? total + (i - pos) : pos;
     P.row_dest[i] = dest;
@@ -784,6 +787,7 @@ __global__ __launch_bounds__(BLOCK) void k_tail(
         if (!stop) idx_next[pos] = g;
         if (stop && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
         P.surv_pos[i] = stop ? -1 : pos;
+        if (stop) *reinterpret_cast<int2 *>(P.stop_list + 2 * (size_t)(i - pos)) = int2{i, g};
         int dest = i;
         if (order == TTL_ORDER_PARTITION) dest = stop ? total + (i - pos) : pos;
         P.row_dest[i] = dest;
@@ -1167,7 +1171,7 @@ size_t ttl_env_workspace_bytes(int32_t n_max) {
     b += 6 * align_up(n * sizeof(int), 256);  // rank, surv_pos, row_dest, proc_rank, proc x2
     b += 2 * align_up(n * 4 * sizeof(float), 256); // head, slot_head
     b += align_up(n * 8 * sizeof(float), 256); // last2
-    b += align_up(n * 2 * sizeof(int), 256);   // pos_dest
+    b += 2 * align_up(n * 2 * sizeof(int), 256); // pos_dest, stop_list
     b += align_up(n * sizeof(int), 256);      // slot_dest
     b += 2 * align_up(nb * sizeof(int), 256); // block_counts, proc_counts
     b += 256;                                 // counts
@@ -1416,6 +1420,7 @@ int ttl_env_create(const ttl_env_desc *desc, ttl_env **out) {
     P.slot_head = (float *)w;     w += align_up(n * 4 * sizeof(float), 256);
     P.last2 = (float *)w;         w += align_up(n * 8 * sizeof(float), 256);
     P.pos_dest = (int *)w;        w += align_up(n * 2 * sizeof(int), 256);
+    P.stop_list = (int *)w;       w += align_up(n * 2 * sizeof(int), 256);
     P.slot_dest = (int *)w;       w += align_up(n * sizeof(int), 256);
     P.counts = (int *)w;          w += 256;
     e->order_ws = w;
@@ -1838,10 +1843,9 @@ int ttl_env_harvest(ttl_env *env, const float *state_in, float *state_out,
     return TTL_OK;
 }
 
-int ttl_env_wait_counts(ttl_env *env) {
-    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_wait_counts: null handle");
-    if (!env->counts_pending)
-        return fail(TTL_ERR_STATE, "ttl_env_wait_counts: the last step had no host_counts");
+// blocks until the host_counts of the last step are in the pinned buffer;
+// leaves counts_pending as it is (waiting twice is harmless)
+static int await_counts(ttl_env *env) {
     if (env->counts_pending == 2) {
         // the step's kernel writes {n_continue, n_stopped, seq} into the pinned
         // buffer: poll the sequence word (bounded; then fall back to waiting
@@ -1868,6 +1872,15 @@ int ttl_env_wait_counts(ttl_env *env) {
     } else {
         HIP_TRY(hipEventSynchronize(env->ev_counts));
     }
+    return TTL_OK;
+}
+
+int ttl_env_wait_counts(ttl_env *env) {
+    if (!env) return fail(TTL_ERR_INVALID, "ttl_env_wait_counts: null handle");
+    if (!env->counts_pending)
+        return fail(TTL_ERR_STATE, "ttl_env_wait_counts: the last step had no host_counts");
+    const int rc = await_counts(env);
+    if (rc != TTL_OK) return rc;
     env->counts_pending = 0;
     // the handle now knows the exact number of survivors: the next step must
     // be launched for exactly that many rows
@@ -1875,6 +1888,19 @@ int ttl_env_wait_counts(ttl_env *env) {
         env->n_active = env->host_counts[0];
         env->n_exact = 1;
     }
+    return TTL_OK;
+}
+
+int ttl_env_stopped(ttl_env *env, const int32_t **stop_list, int32_t *n_stopped) {
+    if (!env || !stop_list || !n_stopped)
+        return fail(TTL_ERR_INVALID, "ttl_env_stopped: null argument");
+    if (!env->stepped || !env->counts_pending || !env->host_counts)
+        return fail(TTL_ERR_STATE, "ttl_env_stopped: call it between a step that was given "
+                                   "host_counts and its harvest");
+    const int rc = await_counts(env);
+    if (rc != TTL_OK) return rc;
+    *stop_list = env->P.stop_list;
+    *n_stopped = env->host_counts[1];
     return TTL_OK;
 }
 

@@ -59,6 +59,7 @@ struct EnvParams {
     int *rank;         // [n_max] survivors before this row inside its block
     int *surv_pos;     // [n_max] position among survivors, -1 if stopped
     int *row_dest;     // [n_max] state row written for this active row
+    int *stop_list;    // [n_max][2] {active row, streamline id} of the rows that stopped in the last step, in row order
     int *block_counts; // [ceil(n_max/BLOCK)] survivors per block
     int *proc_rank;    // [n_max] rank of a kept slot of the processing order
     int *proc_counts;  // [ceil(n_max/BLOCK)] kept slots per block

@@ -570,6 +570,8 @@ __device__ __forceinline__ void prefix_state_body(
         if (stop && order == TTL_ORDER_PARTITION) P.lengths[g] = n_pts;
         P.surv_pos[row] = stop ? -1 : pos;
         P.row_dest[row] = dest;
+        if (stop)       // see k_prefix: the stopped rows in row order, for ttl_env_stopped
+            *reinterpret_cast<int2 *>(P.stop_list + 2 * (size_t)(row - pos)) = int2{row, g};
     }
     const float *h = P.hist + (size_t)g * (size_t)(P.max_nb_steps + 1) * 3;
     state_row_dd<LPS, false, MERGE_TAIL>(P, hp.x, hp.y, hp.z, h, n_pts, sub,

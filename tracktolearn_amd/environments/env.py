@@ -243,6 +243,9 @@ class BaseEnv(object):
                     np.asarray(self.affine_vox2rasmm, np.float64)[:3, :3]
             self._oracle_lin = None if np.allclose(lin, np.eye(3)) else \
                 torch.from_numpy(lin.T.astype(np.float32)).to(self.device)
+            #: the same matrix as host floats, row-major (ttl_oracle_segments)
+            self._oracle_lin_host = None if self._oracle_lin is None else \
+                [float(v) for v in lin.T.astype(np.float32).ravel()]
 
         self._destroy_handle()
         self._n_max = 0

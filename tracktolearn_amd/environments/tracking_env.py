@@ -440,7 +440,13 @@ class TrackingEnvironment(BaseEnv):
         points: ORACLE bit where the score is < 0.5.  None before that."""
         if not n_points > self.min_nb_steps * 5:
             return None
-        scores = self._oracle.predict(self._oracle_points(None, n_points))
+        if self._oracle_fast():
+            # the active rows' histories straight from the library's buffer
+            scores, _ = self._oracle.predict_history(
+                self._buf_streamlines, self._idx_view(n).data_ptr(), 1, n, n_points,
+                self._oracle_lin_host)
+        else:
+            scores = self._oracle.predict(self._oracle_points(None, n_points))
         from tracktolearn_amd.environments.stopping_criteria import StoppingFlags
         return (scores < 0.5).to(torch.uint8) * \
             StoppingFlags.STOPPING_ORACLE.value
@@ -452,6 +458,8 @@ class TrackingEnvironment(BaseEnv):
         returns the oracle term (or None when nothing was scored)."""
         if not n_points > self.min_nb_steps:
             return None
+        if self._oracle_fast():
+            return self._oracle_reward_fast(n, n_points, reward)
         rows = torch.nonzero(done).squeeze(1)         # host sync: count of dones
         if rows.numel() == 0:
             return None
@@ -459,6 +467,37 @@ class TrackingEnvironment(BaseEnv):
         term = torch.zeros(n, dtype=torch.float64, device=self.device)
         term[rows] = (scores > 0.5).double() * float(self.oracle_bonus)
         reward += term
+        return term
+
+    #: the oracle path as library calls (``ttl_env_stopped`` ->
+    #: ``ttl_oracle_segments`` -> the fused network -> ``ttl_oracle_bonus``: four
+    #: launches and the wait for the 8-byte counts that ``harvest()`` needs
+    #: anyway) instead of some twenty torch ops behind a ``nonzero`` sync;
+    #: ``TTL_ORACLE_FAST=0`` or a network the fused kernel does not support keep
+    #: the torch path
+    oracle_fast = os.environ.get('TTL_ORACLE_FAST', '1') != '0'
+
+    def _oracle_fast(self):
+        return self.oracle_fast and getattr(self._oracle, 'net', None) is not None
+
+    def _oracle_reward_fast(self, n, n_points, reward):
+        """``_oracle_reward`` on the rows ``ttl_env_stopped`` lists (the rows
+        ``nonzero(done)`` finds, in the same order)."""
+        import ctypes as C
+        lst, n_stop = C.c_void_p(), C.c_int32()
+        _lib.check(self._lib.ttl_env_stopped(self._handle, C.byref(lst), C.byref(n_stop)),
+                   'ttl_env_stopped')
+        n_stop = n_stop.value
+        if n_stop == 0:
+            return None
+        # ids: the odd words of {row, id} pairs
+        scores, n_scored = self._oracle.predict_history(
+            self._buf_streamlines, lst.value + 4, 2, n_stop, n_points, self._oracle_lin_host)
+        term = torch.empty(n, dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.ttl_oracle_bonus(
+            scores.data_ptr(), n_scored, lst.value, n_stop, float(self.oracle_bonus), n,
+            term.data_ptr(), reward.data_ptr(), self._stream()), 'ttl_oracle_bonus')
+        self._keep_alive_reward = scores
         return term
 
     def step(self, actions):

@@ -106,6 +106,52 @@ class OracleSingleton:
         """Forget the process-wide instance (tests)."""
         cls._self = None
 
+    def _spans(self, n):
+        """Row ranges the reference evaluates (oracle.py:62-84): one batch when
+        n <= batch_size, otherwise the full batches only (the partial last one
+        keeps score 0) unless ``drop_tail`` is off."""
+        bs = self.batch_size
+        if n <= bs:
+            return [(0, n)]
+        spans = [(i * bs, (i + 1) * bs) for i in range(n // bs)]
+        if not self.drop_tail and n % bs:
+            spans.append((n // bs * bs, n))
+        return spans
+
+    def predict_history(self, history, ids, id_stride, n, n_points, lin=None):
+        """``predict`` for rows of the env's history buffer, without the
+        intermediate tensors: streamline ``ids[r * id_stride]`` (device int32
+        pointer; None: row r) of ``history`` (rows of (max_nb_steps + 1) x 3
+        float32), its first ``n_points`` points, mapped by the 3x3 ``lin`` (host
+        floats, p @ lin) when given.  Two launches per batch -- gather + map +
+        resample + difference (``ttl_oracle_segments``), then the network --
+        and only with the fused network.  Returns ``(scores, n_scored)``: rows
+        from ``n_scored`` on were not evaluated (the reference's partial last
+        batch) and hold 0."""
+        import ctypes as C
+
+        from tracktolearn_amd import _lib
+        if self.net is None:
+            raise _lib.TTLError('predict_history needs the fused network')
+        lib = _lib.load()
+        spans = self._spans(n)
+        n_scored = spans[-1][1]
+        dirs = torch.empty((n_scored, 127, 3), dtype=torch.float32, device=self.device)
+        lin_c = None
+        if lin is not None:
+            lin_c = (C.c_float * 9)(*[float(v) for v in lin])
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.ttl_oracle_segments(
+                history.data_ptr(), history.stride(0), ids, id_stride, n_scored, n_points,
+                lin_c, 128, dirs.data_ptr(), stream), 'ttl_oracle_segments')
+        if len(spans) == 1 and n_scored == n:
+            return self.net(dirs), n
+        result = torch.zeros(n, dtype=torch.float32, device=self.device)
+        for lo, hi in spans:
+            result[lo:hi] = self.net(dirs[lo:hi])
+        return result, n_scored
+
     def predict(self, points, lengths=None):
         """Scores (N,) float32 on the device for a padded batch of
         streamlines ``points`` (N, L, 3); ``lengths`` defaults to L for every
@@ -118,14 +164,7 @@ class OracleSingleton:
         if lengths is None:
             lengths = torch.full((n,), points.shape[1], dtype=torch.long,
                                  device=self.device)
-        bs = self.batch_size
-        n_full = n // bs
-        if n <= bs:
-            spans = [(0, n)]
-        else:
-            spans = [(i * bs, (i + 1) * bs) for i in range(n_full)]
-            if not self.drop_tail and n % bs:
-                spans.append((n_full * bs, n))
+        spans = self._spans(n)
         autocast = (torch.autocast('cuda') if self.device.type == 'cuda'
                     else contextlib.nullcontext())
         for lo, hi in spans:
@@ -139,7 +178,7 @@ class OracleSingleton:
             if padded != rows:
                 if self._pad_buf is None or self._pad_buf.shape[0] < padded or \
                         self._pad_buf.shape[1:] != dirs.shape[1:]:
-                    self._pad_buf = torch.zeros((max(padded, bs),) + tuple(dirs.shape[1:]),
+                    self._pad_buf = torch.zeros((max(padded, self.batch_size),) + tuple(dirs.shape[1:]),
                                                 dtype=dirs.dtype, device=dirs.device)
                 self._pad_buf[:rows].copy_(dirs)
                 self._pad_buf[rows:padded].zero_()
