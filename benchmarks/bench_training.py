@@ -88,6 +88,11 @@ def _instrument_oracle(env, phases):
     net = orc.net                     # the fused kernel (oracles/fused_net.py), if in use
 
     def timed_net(x):
+        # (with the oracle path as library calls -- env.oracle_fast -- the resampler
+        # above is not called: ttl_oracle_segments is part of the env step's rest)
+        if env._oracle_fast():
+            rows['scored'] += int(x.shape[0])
+            rows['batches'] += 1
         with phases.span('oracle_transformer'):
             return net(x)
     orc._resample, orc.model.forward = timed_resample, timed_forward

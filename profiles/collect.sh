@@ -51,6 +51,12 @@ cp $(find $O/learner -name "*kernel_stats.csv" | head -1) $R/${tag}_learner_kern
 python3 profiles/learner_trace.py $O/learner > $R/${tag}_learner_update_trace.txt
 tail -1 $O/learner.json > $R/${tag}_learner_under_rocprof.json
 rm -rf $O/learner
+# ... config 5's training step on one GPU's shard (oracle bonus on: ttl_oracle_segments,
+# k_oracle_net_wg, k_oracle_bonus, k_replay_add next to the update's kernels)
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -- python3 benchmarks/bench_training.py --config c5 > $O/c5.json 2> $O/c5.log
+cp $(find $O/c5 -name "*kernel_stats.csv" | head -1) $R/${tag}_config5_kernel_stats.csv
+tail -1 $O/c5.json > $R/${tag}_config5_under_rocprof.json
+rm -rf $O/c5
 # ... and the oracle network (config 5): fused kernel against the autocast module, counters
 $T python3 benchmarks/bench_oracle_net.py > $R/${tag}_oracle_net_bench.jsonl 2> /dev/null
 bash profiles/collect_pmc_oracle_net.sh $tag > /dev/null 2>&1 || true
