@@ -278,3 +278,39 @@ def test_oracle_segments_kernel():
     assert lib.ttl_oracle_segments(hist.data_ptr(), 3 * 10, None, 1, 9, 50, None, 128,
                                    got.data_ptr(), stream) == _lib.ERR_INVALID
 
+
+@pytest.mark.gpu
+def test_oracle_bonus_kernel():
+    """`ttl_oracle_bonus`: term = 0 everywhere, `bonus` at the listed rows whose
+    score is > 0.5 -- rows from n_scored on were never scored (the reference's
+    partial last batch, oracle.py:62-84) and get nothing --, reward += term
+    (oracle_reward.py:84-93)."""
+    import ctypes as C
+
+    from tracktolearn_amd import _lib
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(8)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for n, n_stop, n_scored in ((1, 1, 1), (1000, 300, 300), (5000, 4500, 4096), (70, 0, 0),
+                                (513, 513, 0)):
+        rows = torch.sort(torch.randperm(n, generator=g)[:n_stop]).values
+        ids = torch.randint(0, 10 ** 6, (n_stop,), generator=g)
+        pairs = torch.stack([rows, ids], 1).int().contiguous().to(dev)
+        scores = torch.rand(max(n_stop, 1), generator=g)
+        scores[::7] = 0.5                                   # exactly 0.5 earns nothing
+        reward0 = torch.randn(n, generator=g, dtype=torch.float64)
+        reward = reward0.clone().to(dev)
+        term = torch.full((n,), 3.25, dtype=torch.float64, device=dev)
+        sc = scores.to(dev)
+        _lib.check(lib.ttl_oracle_bonus(sc.data_ptr(), n_scored, pairs.data_ptr(), n_stop, 10.0,
+                                        n, term.data_ptr(), reward.data_ptr(), stream), 'bonus')
+        want = torch.zeros(n, dtype=torch.float64)
+        hit = (scores[:n_stop] > 0.5)
+        hit[n_scored:] = False
+        want[rows] = hit.double() * 10.0
+        assert torch.equal(term.cpu(), want)
+        assert torch.equal(reward.cpu(), reward0 + want)
+    assert lib.ttl_oracle_bonus(sc.data_ptr(), 5, pairs.data_ptr(), 4, 10.0, 10, term.data_ptr(),
+                                reward.data_ptr(), stream) == _lib.ERR_INVALID
+

@@ -246,7 +246,8 @@ int ttl_oracle_segments(const float *history, int64_t row_pitch, const int32_t *
 int ttl_oracle_bonus(const float *scores, int32_t n_scored, const int32_t *stop_list,
                      int32_t n_stopped, double bonus, int32_t n_active, double *term,
                      double *reward, void *hip_stream) {
-    if (!scores || !stop_list || !term || !reward || n_stopped < 0 || n_scored < 0 ||
+    if (!term || !reward || n_stopped < 0 || n_scored < 0 ||
+        (n_stopped > 0 && (!scores || !stop_list)) ||
         n_scored > n_stopped || n_stopped > n_active)
         return fail(TTL_ERR_INVALID, "ttl_oracle_bonus: bad arguments");
     hipStream_t s = (hipStream_t)hip_stream;
