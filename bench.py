@@ -1019,7 +1019,7 @@ def main(argv=None):
                      'n_actor=65536, batch 4096, 96^3x45 volume, n_dirs=4, alignment reward; '
                      'train_step_ms = policy forward + env step + replay add + sample + '
                      'update + harvest, 24 steps after warm-up (freshly initialised policy); '
-                     'update_ms = SACAuto.update alone (fused schedule: 12 fp32 GEMMs + the '
+                     'update_ms = SACAuto.update alone (fused schedule: 16 fp32 GEMMs + the '
                      'learner kernels of libttl_hip.so); roofline = its FLOP / update_ms / '
                      'fp32 MFMA peak; graphed_update = the same replayed from a HIP graph; '
                      'phases_ms_per_step = HIP-event brackets; fp32')

@@ -249,7 +249,7 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
         flops = fl.flops_per_update(batch)
         tf = flops['issued'] / (out['update_ms'] * 1e-3) / 1e12
         out['roofline'] = {
-            'bound': 'mfma', 'kernel': 'SACAuto.update (12 fp32 GEMMs on hipBLASLt + the '
+            'bound': 'mfma', 'kernel': 'SACAuto.update (16 fp32 GEMMs on hipBLASLt + the '
                                        'learner kernels of libttl_hip.so)',
             'achieved': tf, 'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
             'frac': tf / FP32_MFMA_PEAK_TF, 'traffic': None, 'dtype': 'f32',

@@ -11,7 +11,7 @@
  * MI355X learner (tracktolearn_amd/algorithms/shared/fused.py) keeps the dense
  * layers on PyTorch-ROCm's fp32 MFMA GEMMs (north_star) and issues the rest as
  * the hand-written kernels below: a manual forward/backward with the same
- * arithmetic, 12 GEMMs + 14 of these launches per update at
+ * arithmetic, 16 GEMMs + 15 of these launches per update at
  * two hidden layers.
  *
  * Conventions: as include/ttl_hip.h -- plain C, device pointers are borrowed,

@@ -21,7 +21,7 @@ hand-scheduled forward/backward:
 * **batching**: the rows the three forwards consume come from one buffer
   ``xs`` [3B x ld]: rows [0,B) = (s, a), [B,2B) = (s, pi(s)), [2B,3B) =
   (s', pi(s')); the actor runs once on rows [B,3B) (2B rows), the online
-  critics once on rows [0,2B), the target critics on rows [2B,3B): 12 GEMMs
+  critics once on rows [0,2B), the target critics on rows [2B,3B): 16 GEMMs
   instead of ~40, all with 4 096-8 192 rows.
 * **everything that is not a dense GEMM** is a hand-written HIP kernel of
   libttl_hip.so (include/ttl_learner.h): the 6-wide actor head with the
