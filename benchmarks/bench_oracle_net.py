@@ -39,6 +39,14 @@ def timeit(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
+def kernel_name(rows):
+    """Which of the two kernels ttl_oracle_net_forward picks (TTL_ORACLE_NET_WG=1 / 0
+    force one; default: one workgroup per streamline up to 512 rows)."""
+    force = os.environ.get('TTL_ORACLE_NET_WG')
+    wg = rows <= 512 if force is None else force != '0'
+    return 'workgroup per streamline' if wg else 'wavefront per streamline'
+
+
 def main():
     from tracktolearn_amd.oracles.fused_net import FusedOracleNet
     from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
@@ -57,7 +65,7 @@ def main():
         t_fused = timeit(lambda: net(dirs), 20 if rows <= 4096 else 5)
         t_mod = timeit(module, 5 if rows <= 4096 else 2)
         print(json.dumps({
-            'rows': rows, 'kernel': 'workgroup per streamline' if rows <= 512 else 'wavefront per streamline',
+            'rows': rows, 'kernel': kernel_name(rows),
             'fused_ms': round(t_fused * 1e3, 4), 'module_autocast_ms': round(t_mod * 1e3, 3),
             'speedup': round(t_mod / t_fused, 1),
             'fused_TFLOPs_issued': round(rows * issued / t_fused / 1e12, 1),
