@@ -321,8 +321,7 @@ def test_config3_update_on_gpu_matches_cpu(config3_run):
 # --------------------------------------------------------------------------
 # config 5 (one GPU's shard)
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize('fast', [True, False], ids=['library_calls', 'torch_ops'])
-def test_config5_shard_oracle_bonus_and_stopping(tmp_path, monkeypatch, fast):
+def test_config5_shard_oracle_bonus_and_stopping(tmp_path):
     """16 384 streamlines on 96^3, reward on, oracle_bonus 10, oracle batches
     of 4 096 (the default): the sparse bonus on the rows that just stopped and
     the ORACLE stop bit on all active rows, re-derived on the CPU with a
@@ -334,8 +333,9 @@ def test_config5_shard_oracle_bonus_and_stopping(tmp_path, monkeypatch, fast):
     from tracktolearn_amd.oracles.oracle import OracleSingleton
     from tracktolearn_amd.oracles.transformer_oracle import (
         TransformerOracle, save_random_checkpoint)
-    # the oracle path as four library calls (default) / as torch ops
-    monkeypatch.setattr(TrackingEnvironment, 'oracle_fast', fast)
+    # (the oracle path as library calls, the default; the torch ops they replace are
+    # held equal to them by test_oracle_path_as_library_calls_equals_the_torch_ops)
+    assert TrackingEnvironment.oracle_fast
     N, K, BS = 16384, 4, 4096
     ck = save_random_checkpoint(str(tmp_path / 'o.ckpt'), n_head=4, n_layers=4,
                                 seed=5)
