@@ -109,13 +109,40 @@ __device__ __forceinline__ void layer_norm(f16x &x, const float *g, const float 
     for (int a = 0; a < 16; ++a) x[a] = (x[a] - mean) * rstd * gg[a] + bb[a];
 }
 
+// b_1 of a layer (ff floats, [chunk][2 halves][16]) staged in LDS by the whole workgroup:
+// the feed-forward loop reads 64 bytes of it per lane and chunk, the same bytes in every lane
+// of a half -- through the vector L1 that costs as much of its 64 B/clk as the weights
+// themselves (a dwordx4 load occupies it for 16 clocks wherever its lanes point), from LDS it
+// is a broadcast read on a pipe the kernel leaves idle.  Two buffers, one barrier per layer:
+// a wave can only reach the write of layer l + 2 after every wave has passed the barrier of
+// layer l + 1, i.e. finished reading layer l.
+__device__ __forceinline__ const float *stage_b1(float *lds, const NetArgs &P, int layer) {
+    const int ff = P.ff_chunks * 32;
+    float *dst = lds + (layer & 1) * ff;
+    const float *b1 = P.wf + (long long)layer * P.wf_stride + 288;
+    const float4 *src = reinterpret_cast<const float4 *>(b1);
+    for (int i = threadIdx.x; i < ff / 4; i += blockDim.x)
+        reinterpret_cast<float4 *>(dst)[i] = src[i];
+    __syncthreads();
+    return dst;
+}
+
+__device__ __forceinline__ void load_bias(const float *b1s, int c, int hi, float (&bias)[16]) {
+    const float4 *q = reinterpret_cast<const float4 *>(b1s + c * 32 + hi * 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 v = q[k];
+        bias[4 * k + 0] = v.x; bias[4 * k + 1] = v.y; bias[4 * k + 2] = v.z; bias[4 * k + 3] = v.w;
+    }
+}
+
 // One encoder layer on the wave's streamline.  NQ = 4: all four token tiles; NQ = 1 (the
 // last layer): keys and values of all tokens, but queries, out-projection, feed-forward and
 // LayerNorms of the first tile only (the head reads token 0).  A compile-time NQ keeps the
 // tile loops free of branches, so the scheduler interleaves the tiles' MFMA chains.
 template <int NHEAD, int NQ>
 __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, int layer,
-                                              int lane, int n, int hi) {
+                                              int lane, int n, int hi, float *lds) {
     constexpr int DH = 32 / NHEAD;
     const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
     const float *WF = P.wf + (long long)layer * P.wf_stride;
@@ -129,7 +156,7 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
     const float *bo = WF + 96;              // [2][16]
     const float *g1 = WF + 128, *be1 = WF + 160;
     const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
-    const float *b1 = WF + 288;             // [C][2][16]
+    const float *b1s = stage_b1(lds, P, layer);     // b_1 [C][2][16], in LDS
 
     // ---- Q^T, K^T [features x tokens] and V [tokens x features]
     h8 QB[NQ][2], KA[NT][2], VA[NT][2];
@@ -244,22 +271,14 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
     }
     h8 w1a = W1[lane], w1b = W1[64 + lane], w2a = W2[lane], w2b = W2[64 + lane];
     float bias[16];
-    {
-        const float *q = b1 + hi * 16;
-#pragma unroll
-        for (int a = 0; a < 16; ++a) bias[a] = q[a];
-    }
+    load_bias(b1s, 0, hi, bias);
     for (int c = 0; c < P.ff_chunks; ++c) {
         // prefetch the next chunk's weights and bias while this one is multiplied
         const int cn = c + 1 < P.ff_chunks ? c + 1 : c;
         const h8 n1a = W1[(long long)cn * 128 + lane], n1b = W1[(long long)cn * 128 + 64 + lane];
         const h8 n2a = W2[(long long)cn * 128 + lane], n2b = W2[(long long)cn * 128 + 64 + lane];
         float nbias[16];
-        {
-            const float *q = b1 + (long long)cn * 32 + hi * 16;
-#pragma unroll
-            for (int a = 0; a < 16; ++a) nbias[a] = q[a];
-        }
+        load_bias(b1s, cn, hi, nbias);
         // the tiles' chains side by side: GEMM 1 of every tile (the bias rides in as the
         // accumulator's initial value), the fp16 round + ReLU of every tile, GEMM 2
         f16x d1[NQ];
@@ -302,9 +321,13 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
 
 template <int NHEAD>
 __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
+    extern __shared__ __align__(16) float b1_lds[];              // [2][ff]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long row = (long long)blockIdx.x * 4 + wv;        // one wave per streamline
-    if (row >= P.n) return;
+    long long row = (long long)blockIdx.x * 4 + wv;              // one wave per streamline
+    // (a wave past the end works on the last streamline again and stores nothing: the
+    // workgroup's barriers need every wave)
+    const bool live = row < P.n;
+    if (!live) row = P.n - 1;
     const int n = lane & 31, hi = lane >> 5;
     const float *dirs = P.dirs + row * (127 * 3);
 
@@ -338,8 +361,8 @@ __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
     }
 
     for (int layer = 0; layer + 1 < P.n_layers; ++layer)
-        encoder_layer<NHEAD, NT>(hT, P, layer, lane, n, hi);
-    encoder_layer<NHEAD, 1>(hT, P, P.n_layers - 1, lane, n, hi);
+        encoder_layer<NHEAD, NT>(hT, P, layer, lane, n, hi, b1_lds);
+    encoder_layer<NHEAD, 1>(hT, P, P.n_layers - 1, lane, n, hi, b1_lds);
 
     // ---- head on the CLS position (token 0 = tile 0, lane column 0 of both halves)
     float dot = 0.f;
@@ -350,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
             dot += (float)(_Float16)hT[0][a] * (float)(_Float16)w[a];
     }
     dot += swap_halves(dot);
-    if (lane == 0) {
+    if (lane == 0 && live) {
         float y = (float)(_Float16)(dot + (float)(_Float16)P.head[32]);
         y = 1.f / (1.f + expf(-y));
         P.out[row] = (float)(_Float16)y;
@@ -369,7 +392,8 @@ __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
 template <int NHEAD>
 __device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
                                                   const h8 (*kv)[NT][2][64], const NetArgs &P,
-                                                  int layer, int lane, int n, int hi) {
+                                                  int layer, int lane, int n, int hi,
+                                                  const float *b1s) {
     constexpr int DH = 32 / NHEAD;
     const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
     const float *WF = P.wf + (long long)layer * P.wf_stride;
@@ -379,7 +403,6 @@ __device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
     const float *bo = WF + 96;
     const float *g1 = WF + 128, *be1 = WF + 160;
     const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
-    const float *b1 = WF + 288;
 
     h8 KA[NT][2], VA[NT][2];
 #pragma unroll
@@ -468,9 +491,7 @@ __device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
         w[1] = W1[(long long)c * 128 + 64 + lane];
         w[2] = W2[(long long)c * 128 + lane];
         w[3] = W2[(long long)c * 128 + 64 + lane];
-        const float *q = b1 + (long long)c * 32 + hi * 16;
-#pragma unroll
-        for (int a = 0; a < 16; ++a) bias[a] = q[a];
+        load_bias(b1s, c, hi, bias);
     };
     load(0, wA, biasA);
     load(P.ff_chunks > 1 ? 1 : 0, wB, biasB);
@@ -543,6 +564,7 @@ __device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
 template <int NHEAD>
 __global__ __launch_bounds__(256, 2) void k_oracle_net_wg(NetArgs P) {
     __shared__ h8 kv[2][NT][2][64];                 // keys | values: [tile][k-step][lane], 16 KB
+    extern __shared__ __align__(16) float b1_lds[]; // [2][ff], see stage_b1
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // wave w owns token tile w
     const long long row = blockIdx.x;               // one workgroup per streamline
     const int n = lane & 31, hi = lane >> 5;
@@ -600,8 +622,8 @@ __global__ __launch_bounds__(256, 2) void k_oracle_net_wg(NetArgs P) {
             add_rows(q, bqk, hi);
             to_frags(q, QB);
         }
-        __syncthreads();
-        if (goes_on) attention_ff_tile<NHEAD>(hT, QB, kv, P, layer, lane, n, hi);
+        const float *b1s = stage_b1(b1_lds, P, layer);      // its barrier also publishes kv
+        if (goes_on) attention_ff_tile<NHEAD>(hT, QB, kv, P, layer, lane, n, hi, b1s);
         __syncthreads();                            // kv is rewritten by the next layer
     }
 
@@ -632,6 +654,9 @@ int ttl_oracle_net_forward(const float *dirs, int64_t n, const void *packed_half
     if (n <= 0 || n_layers <= 0 || ff_dim <= 0 || ff_dim % 32)
         return fail(TTL_ERR_INVALID, "ttl_oracle_net_forward: bad shape (n %lld, layers %d, ff %d)",
                     (long long)n, n_layers, ff_dim);
+    if (ff_dim > 8192)      // b_1 of two layers in LDS: 8 ff bytes of the default 64 KB
+        return fail(TTL_ERR_UNSUPPORTED, "ttl_oracle_net_forward: feed-forward width %d > 8192",
+                    ff_dim);
     if (n_head != 1 && n_head != 2 && n_head != 4)
         return fail(TTL_ERR_UNSUPPORTED, "ttl_oracle_net_forward: 1, 2 or 4 heads (got %d)", n_head);
     if (((uintptr_t)packed_half & 15u) || ((uintptr_t)packed_float & 15u))
@@ -648,16 +673,17 @@ int ttl_oracle_net_forward(const float *dirs, int64_t n, const void *packed_half
         return v ? atoi(v) : -1;
     }();
     const bool wg = wg_mode == 1 || (wg_mode != 0 && n <= TTL_ORACLE_NET_WG_MAX_ROWS);
+    const size_t lds = (size_t)2 * ff_dim * sizeof(float);          // b_1, two layers
     if (wg) {
         const dim3 grid((unsigned)n), block(256);
-        if (n_head == 1) k_oracle_net_wg<1><<<grid, block, 0, s>>>(P);
-        else if (n_head == 2) k_oracle_net_wg<2><<<grid, block, 0, s>>>(P);
-        else k_oracle_net_wg<4><<<grid, block, 0, s>>>(P);
+        if (n_head == 1) k_oracle_net_wg<1><<<grid, block, lds, s>>>(P);
+        else if (n_head == 2) k_oracle_net_wg<2><<<grid, block, lds, s>>>(P);
+        else k_oracle_net_wg<4><<<grid, block, lds, s>>>(P);
     } else {
         const dim3 grid((unsigned)((n + 3) / 4)), block(256);
-        if (n_head == 1) k_oracle_net<1><<<grid, block, 0, s>>>(P);
-        else if (n_head == 2) k_oracle_net<2><<<grid, block, 0, s>>>(P);
-        else k_oracle_net<4><<<grid, block, 0, s>>>(P);
+        if (n_head == 1) k_oracle_net<1><<<grid, block, lds, s>>>(P);
+        else if (n_head == 2) k_oracle_net<2><<<grid, block, lds, s>>>(P);
+        else k_oracle_net<4><<<grid, block, lds, s>>>(P);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -12,7 +12,7 @@ scores a batch of segment-vector sequences in one launch.
 
 Supported: the reference's architecture as it is instantiated (d_model 32,
 128 tokens = 127 segments + CLS, ReLU post-norm encoder layers, no final
-norm, feed-forward width a multiple of 32) with 1, 2 or 4 heads.  Anything
+norm, feed-forward width a multiple of 32 up to 8 192) with 1, 2 or 4 heads.  Anything
 else keeps the PyTorch-ROCm module (``OracleSingleton`` checks
 ``FusedOracleNet.supports``).  Arithmetic follows ``torch.autocast(fp16)``,
 what the reference runs the network under (oracles/oracle.py:76): fp16
@@ -125,6 +125,7 @@ class FusedOracleNet:
                     and all(isinstance(m, nn.TransformerEncoderLayer) for m in layers)
                     and l0.self_attn.num_heads in (1, 2, 4) and l0.self_attn.batch_first
                     and not l0.norm_first and l0.linear1.out_features % 32 == 0
+                    and l0.linear1.out_features <= 8192
                     and getattr(l0.activation, '__name__', '') == 'relu'
                     and l0.self_attn.in_proj_weight is not None
                     and abs(l0.norm1.eps - 1e-5) < 1e-12
