@@ -109,6 +109,53 @@ __device__ __forceinline__ void layer_norm(f16x &x, const float *g, const float 
     for (int a = 0; a < 16; ++a) x[a] = (x[a] - mean) * rstd * gg[a] + bb[a];
 }
 
+// S <- 2^((S - m) scale) for the 64 scores of a lane (its query against 64 of the 128 keys),
+// returns their sum over all 128 keys.  Two scores per instruction: S scale - m scale as one
+// v_pk_fma_f32, the running sum as v_pk_add_f32 (the library is built with -ffp-contract=off,
+// so the compiler may not form the fma itself; the softmax is the largest block of VALU work
+// in the kernel, and the VALU, not the MFMA pipe, is what the kernel waits for).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// (x[8 s .. 8 s + 7] * inv) as an fp16 operand fragment, two elements per instruction in the
+// register pairs the accumulator tile already has (written out so: left to itself the
+// vectoriser pairs elements (1,2), (3,4), (5,6), and pays for it in register copies and
+// v_alignbit shuffles -- a quarter of the attention block's instructions)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h8 scaled_frag(const f16x &x, int s, float inv) {
+    const f2 i2 = {inv, inv};
+    h2 q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f2 v = f2{x[8 * s + 2 * j], x[8 * s + 2 * j + 1]} * i2;
+        q[j] = __builtin_convertvector(v, h2);
+    }
+    return h8{q[0].x, q[0].y, q[1].x, q[1].y, q[2].x, q[2].y, q[3].x, q[3].y};
+}
+
+__device__ __forceinline__ float softmax_numerators(f16x (&S)[NT], float m, float scale) {
+    const f2 sc = {scale, scale};
+    const float nm = -m * scale;
+    const f2 off = {nm, nm};
+    f2 l2 = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int a = 0; a < 16; a += 2) {
+            const f2 s2 = {S[mt][a], S[mt][a + 1]};
+            const f2 e = __builtin_elementwise_fma(s2, sc, off);
+            f2 p;
+            p.x = __builtin_amdgcn_exp2f(e.x);
+            p.y = __builtin_amdgcn_exp2f(e.y);
+            S[mt][a] = p.x;
+            S[mt][a + 1] = p.y;
+            l2 += p;
+        }
+    float l = l2.x + l2.y;
+    l += swap_halves(l);
+    return l;
+}
+
 // b_1 of a layer (ff floats, [chunk][2 halves][16]) staged in LDS by the whole workgroup:
 // the feed-forward loop reads 64 bytes of it per lane and chunk, the same bytes in every lane
 // of a half -- through the vector L1 that costs as much of its 64 B/clk as the weights
@@ -217,16 +264,7 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
 #pragma unroll
                 for (int a = 0; a < 16; ++a) m = fmaxf(m, S[mt][a]);
             m = fmaxf(m, swap_halves(m));
-            float l = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    const float p = __builtin_amdgcn_exp2f((S[mt][a] - m) * scale);
-                    S[mt][a] = p;
-                    l += p;
-                }
-            l += swap_halves(l);
+            const float l = softmax_numerators(S, m, scale);
             const float inv = 1.f / l;
             // O^T += V^T (rows of head h only) . P^T
             const bool mine = (n / DH) == h;        // this lane's V column belongs to head h
@@ -234,9 +272,7 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
             for (int mt = 0; mt < NT; ++mt) {
                 h8 PB[2];
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) PB[s][j] = (_Float16)(S[mt][8 * s + j] * inv);
+                for (int s = 0; s < 2; ++s) PB[s] = scaled_frag(S[mt], s, inv);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     h8 va = VA[mt][s];
@@ -274,7 +310,11 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
     load_bias(b1s, 0, hi, bias);
     for (int c = 0; c < P.ff_chunks; ++c) {
         // prefetch the next chunk's weights and bias while this one is multiplied
+#if defined(TTL_EXP_FF_SAME_CHUNK)      // timing experiment (benchmarks/micro/oracle_ff_probe.py):
+        const int cn = 0;               // every chunk re-reads chunk 0 -- L1-resident weights
+#else
         const int cn = c + 1 < P.ff_chunks ? c + 1 : c;
+#endif
         const h8 n1a = W1[(long long)cn * 128 + lane], n1b = W1[(long long)cn * 128 + 64 + lane];
         const h8 n2a = W2[(long long)cn * 128 + lane], n2b = W2[(long long)cn * 128 + 64 + lane];
         float nbias[16];
@@ -437,25 +477,14 @@ __device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
 #pragma unroll
             for (int a = 0; a < 16; ++a) m = fmaxf(m, S[mt][a]);
         m = fmaxf(m, swap_halves(m));
-        float l = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const float p = __builtin_amdgcn_exp2f((S[mt][a] - m) * scale);
-                S[mt][a] = p;
-                l += p;
-            }
-        l += swap_halves(l);
+        const float l = softmax_numerators(S, m, scale);
         const float inv = 1.f / l;
         const bool mine = (n / DH) == h;
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             h8 PB[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) PB[s][j] = (_Float16)(S[mt][8 * s + j] * inv);
+            for (int s = 0; s < 2; ++s) PB[s] = scaled_frag(S[mt], s, inv);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 h8 va = VA[mt][s];
