@@ -277,12 +277,20 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
     restore = _instrument_oracle(env, ph)
     ar_orig = None
     if fl is not None and data_parallel:
-        ar_orig = fl._all_reduce
+        # the part of the gradient exchange the compute stream waits for: with
+        # TTL_DP_OVERLAP (default) the critics' all-reduce runs beside the actor's
+        # backward and only `_all_reduce_end` (the waits + the 1/world scaling)
+        # shows; without, `_all_reduce` is the whole exchange
+        ar_orig = (fl._all_reduce, fl._all_reduce_end)
 
         def timed_all_reduce(*extra):
             with ph.span('update_all_reduce'):
-                ar_orig(*extra)
-        fl._all_reduce = timed_all_reduce
+                ar_orig[0](*extra)
+
+        def timed_all_reduce_end(handle):
+            with ph.span('update_all_reduce'):
+                ar_orig[1](handle)
+        fl._all_reduce, fl._all_reduce_end = timed_all_reduce, timed_all_reduce_end
     state = reset()
     torch.cuda.synchronize()
     units = 0
@@ -292,7 +300,7 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
     tot = ph.totals_ms()
     rows = restore()
     if ar_orig is not None:
-        fl._all_reduce = ar_orig
+        fl._all_reduce, fl._all_reduce_end = ar_orig
     phases = {k: v / steps for k, v in tot.items()}
     if oracle:
         phases['env_step_without_oracle_network'] = phases['env_step'] - \

@@ -81,6 +81,33 @@ weights = [p.detach().clone() for p in net.parameters()]
 parallel.broadcast_parameters([net])
 assert all(torch.equal(w, p) for w, p in zip(weights, net.parameters()))
 
+# the fused learner's gradient exchange through RCCL: the critics' arena averaged
+# beside the actor's backward (async all_reduce on the device), or both arenas after
+# the backward -- on one rank either equals the update without a group, bit for bit
+from tracktolearn_amd.algorithms.sac_auto import SACAuto
+from tracktolearn_amd.algorithms.shared import fused as fused_mod
+g = torch.Generator().manual_seed(3)
+Wd, Bt = 37, 256
+batch = [torch.randn(Bt, Wd, generator=g).cuda(), torch.tanh(torch.randn(Bt, 3, generator=g)).cuda(),
+         torch.randn(Bt, Wd, generator=g).cuda(), torch.rand(Bt, generator=g).cuda(),
+         (torch.rand(Bt, generator=g) > 0.2).float().cuda()]
+results = []
+for mode in ('none', 'overlap', 'sequential'):
+    torch.manual_seed(11)
+    alg = SACAuto(Wd, 3, '64-64', n_actors=8, batch_size=Bt, replay_size=100, rng=None,
+                  device=torch.device('cuda:0'))
+    if mode != 'none':
+        fused_mod._FusedNets.dp_overlap = mode == 'overlap'
+        alg.enable_data_parallel()
+    for _ in range(3):
+        alg.update(batch)
+    assert alg._fused is not None
+    results.append(torch.cat([p.detach().reshape(-1) for p in
+                              list(alg.agent.parameters()) + list(alg.target.parameters())
+                              + [alg.log_alpha]]))
+torch.cuda.synchronize()
+assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
+
 # bench.py's reductions on the device
 t = torch.tensor([1.5, 2.5], dtype=torch.float64, device='cuda:0')
 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -101,7 +101,7 @@ def test_ragged_all_gather_world2_gloo():
     assert sorted(results) == [(0, 'ok'), (1, 'ok')], results
 
 
-def _dp_worker(rank, world, port, q, fused=False):
+def _dp_worker(rank, world, port, q, fused=False, overlap=True):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -115,7 +115,10 @@ def _dp_worker(rank, world, port, q, fused=False):
             # the GPU learner's schedule (shared/fused.py: one all-reduce per gradient
             # arena) with the kernels replaced by their torch restatement
             from ref_learner_ops import TorchOps
+            from tracktolearn_amd.algorithms.shared import fused as fused_mod
             alg._fused_ops = TorchOps()
+            # critics' average beside the actor's backward / both after the backward
+            fused_mod._FusedNets.dp_overlap = overlap
         alg.enable_data_parallel()
         g = torch.Generator().manual_seed(7)
         full = [torch.randn(2 * B, W, generator=g),
@@ -147,18 +150,22 @@ def _dp_worker(rank, world, port, q, fused=False):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('fused', [False, True, 'sequential'])
 def test_data_parallel_learner_world2_gloo(fused):
     """Two learner replicas on half batches each == one learner on the whole
     batch: identical replicas, and equal (to rounding) to the single-process
     update started from rank 0's weights.  `fused`: the replicas run the GPU
-    learner's hand-scheduled update (arena all-reduce, deterministic
-    reductions), the single process the autograd formulation."""
+    learner's hand-scheduled update (arena all-reduce -- overlapped with the
+    backward, or 'sequential': both after it --, deterministic reductions), the
+    single process the autograd formulation."""
     from tracktolearn_amd.algorithms.sac_auto import SACAuto
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000 + (37 if fused else 0)
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, fused)) for r in range(2)]
+    overlap = fused != 'sequential'
+    fused = bool(fused)
+    port = 31500 + os.getpid() % 2000 + (37 if fused else 0) + (0 if overlap else 11)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, fused, overlap))
+             for r in range(2)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=180) for _ in procs)

@@ -38,6 +38,7 @@ kernels are required (``_lib.load()`` raises without the library); on the
 CPU (the known-answer tests) SAC keeps the plain autograd update.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -430,6 +431,32 @@ class _FusedNets:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             t /= world
 
+    #: data-parallel replicas: the critics' gradient arena is averaged WHILE the
+    #: actor's backward runs (it is complete before the actor-loss rows leave the
+    #: critics), the actor's while the critics' Adam step runs; ``TTL_DP_OVERLAP=0``:
+    #: both after the backward, one after the other (``_all_reduce``)
+    dp_overlap = os.environ.get('TTL_DP_OVERLAP', '1') != '0'
+
+    def _all_reduce_begin(self, tensors):
+        """Start averaging ``tensors`` over the replicas: the collective is
+        ordered after everything queued on the current stream so far and runs
+        beside what is queued next (RCCL's own stream).  Returns a handle for
+        ``_all_reduce_end``."""
+        import torch.distributed as dist
+        group = self.alg._dp_group
+        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                 for t in tensors]
+        return works, tensors, dist.get_world_size(group)
+
+    def _all_reduce_end(self, handle):
+        """The current stream waits for the collectives of ``handle``; sums ->
+        means."""
+        works, tensors, world = handle
+        for w in works:
+            w.wait()
+        for t in tensors:
+            t /= world
+
 
 class FusedSACUpdate(_FusedNets):
     """One SAC / SACAuto update on ``alg``'s networks (see the module
@@ -568,6 +595,18 @@ class FusedSACUpdate(_FusedNets):
         h0 = self.hq[0]
         torch.mm(self.dzc[0][:B].t(), xs[:B, :S + A],
                  out=W(aq, aq.grad, 0).view(2 * h0, S + A))
+        # the critics' gradients are complete: slabs -> arena (fixed order), and with
+        # data-parallel replicas their average starts here, beside the actor's backward
+        haL, hqL = self.ha[-1], self.hq[-1]
+        segs = [(self.part_q_top, 0, 2 * hqL, Bv(aq, aq.grad, L - 1).view(-1), 1.0),
+                (self.part_q_top, 2 * hqL, 2 * hqL, W(aq, aq.grad, L).view(-1), 1.0),
+                (self.part_q_top, 4 * hqL, 2, Bv(aq, aq.grad, L).view(-1), 1.0)]
+        segs += [(self.part_q[l], 0, 2 * self.hq[l], Bv(aq, aq.grad, l).view(-1), 1.0)
+                 for l in range(L - 1)]
+        ops.colsum_finalize(segs)
+        dp = getattr(alg, '_dp', False)
+        overlap = dp and self.dp_overlap
+        pending_q = self._all_reduce_begin((aq.grad,)) if overlap else None
         ops.actor_head_backward(self.dzc[0][B:], self.hc[0][B:], self.wa, A, xs[B:2 * B, S:],
                                 ld, self.eps, self.ls_raw, log_alpha,
                                 0.0 if self.auto else alg.alpha, self.d_head)
@@ -582,8 +621,7 @@ class FusedSACUpdate(_FusedNets):
                                    self.part_a[l - 1])
         torch.mm(self.dza[0].t(), xs[B:2 * B, :S], out=W(aa, aa.grad, 0))
 
-        # ---- slabs -> gradients (fixed order)
-        haL, hqL = self.ha[-1], self.hq[-1]
+        # ---- the actor's slabs -> gradients (fixed order)
         segs = [(self.part_a_top, 0, haL, Bv(aa, aa.grad, L - 1), 1.0),
                 (self.part_a_top, haL, 2 * A * haL, W(aa, aa.grad, L).view(-1), 1.0),
                 (self.part_a_top, haL + 2 * A * haL, 2 * A, Bv(aa, aa.grad, L), 1.0)]
@@ -593,23 +631,25 @@ class FusedSACUpdate(_FusedNets):
         if want_losses:
             segs.append((self.loss_part, 0, 8, self.loss_out, 1.0 / B))
         ops.colsum_finalize(segs)
-        segs = [(self.part_q_top, 0, 2 * hqL, Bv(aq, aq.grad, L - 1).view(-1), 1.0),
-                (self.part_q_top, 2 * hqL, 2 * hqL, W(aq, aq.grad, L).view(-1), 1.0),
-                (self.part_q_top, 4 * hqL, 2, Bv(aq, aq.grad, L).view(-1), 1.0)]
-        segs += [(self.part_q[l], 0, 2 * self.hq[l], Bv(aq, aq.grad, l).view(-1), 1.0)
-                 for l in range(L - 1)]
-        ops.colsum_finalize(segs)
 
         # ---- data-parallel replicas: one all-reduce per arena
-        if getattr(alg, '_dp', False):
-            self._all_reduce((self.mean_logp,) if self.auto else ())
+        extra = (self.mean_logp,) if self.auto else ()
+        if overlap:
+            # the actor's average runs beside the critics' Adam step
+            pending_a = self._all_reduce_begin((aa.grad,) + extra)
+            self._all_reduce_end(pending_q)
+            ops.adam_polyak(aq.online, aq.grad, aq.m, aq.v, aq.target, self.consts[4:6], alg.tau)
+            self._all_reduce_end(pending_a)
+        elif dp:
+            self._all_reduce(extra)
 
         # ---- temperature, actor, critics: Adam (+ Polyak)
         if self.auto:
             ops.alpha_step(alg.log_alpha.data, alg.log_alpha.grad, self.alpha_m, self.alpha_v,
                            self.mean_logp, alg.target_entropy, self.consts[0:2])
         ops.adam_polyak(aa.online, aa.grad, aa.m, aa.v, aa.target, self.consts[2:4], alg.tau)
-        ops.adam_polyak(aq.online, aq.grad, aq.m, aq.v, aq.target, self.consts[4:6], alg.tau)
+        if not overlap:
+            ops.adam_polyak(aq.online, aq.grad, aq.m, aq.v, aq.target, self.consts[4:6], alg.tau)
         if want_losses:
             lo = self.loss_out
             return {'actor_loss': lo[0], 'critic_loss': lo[1] + lo[2], 'loss_q1': lo[1],
