@@ -204,12 +204,17 @@ def test_fused_oracle_net_matches_the_module(n_head, n_layers, ff):
               f'fused vs autocast {d:.2e}')
         assert float(y32.max() - y32.min()) > 0.02 or n < 257    # the scores do spread
         assert e_fused <= 3 * e_auto + 2e-3 and d <= 4e-3
-    # rows are independent: a row's score does not depend on its batch -- nor on which of
-    # the two kernels scored it (<= 512 rows: one workgroup per streamline, the keys and
-    # values of its four token tiles through LDS; more: one wavefront per streamline)
-    one = net(dirs[100:101])
-    assert torch.equal(one, got[100:101])
-    assert torch.equal(net(dirs[:512]), got[:512]) and torch.equal(net(dirs[512:1100]), got[512:1100])
+    # rows are independent: a row's score does not depend on its batch ...
+    few = net(dirs[:512])
+    assert torch.equal(net(dirs[100:101]), few[100:101])
+    assert torch.equal(net(dirs[512:1100]), got[512:1100])
+    # ... and the two kernels (<= 512 rows: one workgroup per streamline -- keys / values
+    # through LDS, the feed-forward block split over the hidden units with its four partial
+    # sums added in wave order; more: one wavefront per streamline, one accumulator) agree
+    # to the rounding of the fp16 score: the order of a float32 sum is all that differs
+    d = float((few - got[:512]).abs().max())
+    print(f'heads {n_head} layers {n_layers}: workgroup kernel vs wave kernel {d:.2e}')
+    assert d <= 1e-3
 
 
 @pytest.mark.gpu

@@ -238,6 +238,9 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
 #pragma unroll
     for (int nt = 0; nt < NQ; ++nt) {
         f16x OT = zero16();
+#if defined(TTL_EXP_NO_ATTENTION)       // timing experiment: scores / softmax / P.V skipped
+        OT = hT[nt];
+#else
 #pragma unroll
         for (int h = 0; h < NHEAD; ++h) {
             // scores S^T [keys x queries] of head h
@@ -286,6 +289,7 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
                 }
             }
         }
+#endif
         // out-projection on the fp16 attention output, residual, LayerNorm 1
         h8 OB[2];
         to_frags(OT, OB);
@@ -308,10 +312,23 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
     h8 w1a = W1[lane], w1b = W1[64 + lane], w2a = W2[lane], w2b = W2[64 + lane];
     float bias[16];
     load_bias(b1s, 0, hi, bias);
+#if defined(TTL_EXP_NO_FF)                  // timing experiment: one chunk instead of all
+    for (int c = 0; c < 1; ++c) {
+#else
     for (int c = 0; c < P.ff_chunks; ++c) {
+#endif
         // prefetch the next chunk's weights and bias while this one is multiplied
-#if defined(TTL_EXP_FF_SAME_CHUNK)      // timing experiment (benchmarks/micro/oracle_ff_probe.py):
-        const int cn = 0;               // every chunk re-reads chunk 0 -- L1-resident weights
+        // timing experiments (benchmarks/micro/oracle_ff_probe.py + build_variant.py; the
+        // scores of such a build mean nothing): TTL_EXP_FF_SAME_CHUNK re-reads chunk 0 for every
+        // chunk (L1-resident weights), TTL_EXP_FF_NO_LOADS keeps chunk 0's registers and bias
+#if defined(TTL_EXP_FF_NO_LOADS)
+        const h8 n1a = w1a, n1b = w1b, n2a = w2a, n2b = w2b;
+        float nbias[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) nbias[a] = bias[a];
+#else
+#if defined(TTL_EXP_FF_SAME_CHUNK)
+        const int cn = 0;
 #else
         const int cn = c + 1 < P.ff_chunks ? c + 1 : c;
 #endif
@@ -319,6 +336,7 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
         const h8 n2a = W2[(long long)cn * 128 + lane], n2b = W2[(long long)cn * 128 + 64 + lane];
         float nbias[16];
         load_bias(b1s, cn, hi, nbias);
+#endif
         // the tiles' chains side by side: GEMM 1 of every tile (the bias rides in as the
         // accumulator's initial value), the fp16 round + ReLU of every tile, GEMM 2
         f16x d1[NQ];
@@ -430,19 +448,15 @@ __global__ __launch_bounds__(256, 1) void k_oracle_net(NetArgs P) {
 // In the last layer only wave 0 (the tile of token 0) goes on after K / V.
 // ------------------------------------------------------------------------
 template <int NHEAD>
-__device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
-                                                  const h8 (*kv)[NT][2][64], const NetArgs &P,
-                                                  int layer, int lane, int n, int hi,
-                                                  const float *b1s) {
+__device__ __forceinline__ void attention_tile(f16x &hT, const h8 (&QB)[2],
+                                               const h8 (*kv)[NT][2][64], const NetArgs &P,
+                                               int layer, int lane, int n, int hi) {
     constexpr int DH = 32 / NHEAD;
     const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
     const float *WF = P.wf + (long long)layer * P.wf_stride;
     const h8 *Wo = WH + 6 * 64;
-    const h8 *W1 = WH + 8 * 64;
-    const h8 *W2 = W1 + (long long)P.ff_chunks * 2 * 64;
     const float *bo = WF + 96;
     const float *g1 = WF + 128, *be1 = WF + 160;
-    const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
 
     h8 KA[NT][2], VA[NT][2];
 #pragma unroll
@@ -506,93 +520,136 @@ __device__ __forceinline__ void attention_ff_tile(f16x &hT, const h8 (&QB)[2],
 #pragma unroll
     for (int a = 0; a < 16; ++a) hT[a] += o[a];
     layer_norm(hT, g1, be1, hi);
+}
 
-    // feed-forward on this tile, two 32-unit chunks side by side (two independent
-    // MFMA chains in the wave; the partner workgroup fills what is left)
-    h8 fB[2];
-    to_frags(hT, fB);
-    f16x D2 = zero16();
-    const int pairs = P.ff_chunks >> 1;
-    h8 wA[4], wB[4];
-    float biasA[16], biasB[16];
-    auto load = [&](int c, h8 (&w)[4], float (&bias)[16]) {
-        w[0] = W1[(long long)c * 128 + lane];
-        w[1] = W1[(long long)c * 128 + 64 + lane];
-        w[2] = W2[(long long)c * 128 + lane];
-        w[3] = W2[(long long)c * 128 + 64 + lane];
-        load_bias(b1s, c, hi, bias);
+// Feed-forward block of the workgroup's streamline, split over the HIDDEN units: wave w takes
+// the chunks c = w, w + 4, ... for ALL token tiles (NQT = 4; 1 in the last layer, which only
+// feeds token 0's tile) and the four partial sums of a tile meet in LDS.  With the block split
+// over token tiles instead (one tile per wave) every weight fragment fed exactly one MFMA and
+// each wave streamed the whole 256 KB of the layer through the vector L1 -- 1 KB per 32-cycle
+// MFMA and SIMD, twice what it delivers; here a fragment feeds NQT MFMAs and the workgroup
+// reads every weight once.  The partial sums are added in wave order (a fixed order: the
+// scores do not depend on scheduling), which is not the order of the wave-per-streamline
+// kernel's single accumulator -- the two kernels agree to an fp16 ulp of the score, not bit
+// for bit.
+template <int NQT>
+__device__ __forceinline__ void ff_hidden_split(f16x &hT, const h8 (*fbuf)[2][64],
+                                                float4 (*pbuf)[4][64], const NetArgs &P,
+                                                int layer, int lane, int hi, int w,
+                                                const float *b1s) {
+    const h8 *WH = reinterpret_cast<const h8 *>(P.wh) + (long long)layer * P.wh_stride;
+    const float *WF = P.wf + (long long)layer * P.wf_stride;
+    const h8 *W1 = WH + 8 * 64;
+    const h8 *W2 = W1 + (long long)P.ff_chunks * 2 * 64;
+    const float *b2 = WF + 192, *g2 = WF + 224, *be2 = WF + 256;
+    const int C = P.ff_chunks;
+
+    h8 fB[NQT][2];
+    f16x D2[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        fB[t][0] = fbuf[t][0][lane];
+        fB[t][1] = fbuf[t][1][lane];
+        D2[t] = zero16();
+    }
+    auto load = [&](int c, h8 (&wt)[4]) {
+        wt[0] = W1[(long long)c * 128 + lane];
+        wt[1] = W1[(long long)c * 128 + 64 + lane];
+        wt[2] = W2[(long long)c * 128 + lane];
+        wt[3] = W2[(long long)c * 128 + 64 + lane];
     };
-    load(0, wA, biasA);
-    load(P.ff_chunks > 1 ? 1 : 0, wB, biasB);
-    for (int cp = 0; cp < pairs; ++cp) {
-        h8 nA[4], nB[4];
-        float nbA[16], nbB[16];
-        const int c2 = cp + 1 < pairs ? 2 * cp + 2 : 2 * cp;
-        load(c2, nA, nbA);
-        load(c2 + 1, nB, nbB);
-        f16x da, db;
+    h8 wt[4];
+    if (w < C) load(w, wt);
+    for (int c = w; c < C; c += 4) {
+        h8 nw[4];
+        load(c + 4 < C ? c + 4 : c, nw);        // this wave's next chunk, one ahead
+        // two token tiles at a time: two independent MFMA chains, half the transient registers
+        // (the bias comes from LDS again for each pair: four broadcast reads, no registers held)
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            da[a] = biasA[a];
-            db[a] = biasB[a];
-        }
-        da = mfma(wA[0], fB[0], da);
-        db = mfma(wB[0], fB[0], db);
-        da = mfma(wA[1], fB[1], da);
-        db = mfma(wB[1], fB[1], db);
-        h8 FA[2], FB2[2];
+        for (int t0 = 0; t0 < NQT; t0 += 2) {
+            constexpr int one = 1;
+            const int t1 = t0 + one < NQT ? t0 + one : t0;
+            float bias[16];
+            load_bias(b1s, c, hi, bias);
+            f16x da, db;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 u = (_Float16)da[8 * s + j], v = (_Float16)db[8 * s + j];
-                FA[s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
-                FB2[s][j] = v > (_Float16)0.f ? v : (_Float16)0.f;
+            for (int a = 0; a < 16; ++a) {
+                da[a] = bias[a];
+                db[a] = bias[a];
             }
-        D2 = mfma(wA[2], FA[0], D2);
-        D2 = mfma(wA[3], FA[1], D2);
-        D2 = mfma(wB[2], FB2[0], D2);
-        D2 = mfma(wB[3], FB2[1], D2);
+            da = mfma(wt[0], fB[t0][0], da);
+            if (NQT > 1) db = mfma(wt[0], fB[t1][0], db);
+            da = mfma(wt[1], fB[t0][1], da);
+            if (NQT > 1) db = mfma(wt[1], fB[t1][1], db);
+            h8 FA[2], FB2[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wA[k] = nA[k];
-            wB[k] = nB[k];
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // Linear output in fp16, then ReLU
+                    const _Float16 u = (_Float16)da[8 * s + j], v = (_Float16)db[8 * s + j];
+                    FA[s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
+                    FB2[s][j] = v > (_Float16)0.f ? v : (_Float16)0.f;
+                }
+            D2[t0] = mfma(wt[2], FA[0], D2[t0]);
+            if (NQT > 1) D2[t1] = mfma(wt[2], FB2[0], D2[t1]);
+            D2[t0] = mfma(wt[3], FA[1], D2[t0]);
+            if (NQT > 1) D2[t1] = mfma(wt[3], FB2[1], D2[t1]);
         }
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            biasA[a] = nbA[a];
-            biasB[a] = nbB[a];
-        }
+        for (int k = 0; k < 4; ++k) wt[k] = nw[k];
     }
-    if (P.ff_chunks & 1) {                      // an odd last chunk
-        const int c = P.ff_chunks - 1;
-        h8 w[4];
-        float bias[16];
-        load(c, w, bias);
-        f16x d1;
+    // partial sums of the tiles this wave does not own -> LDS (slot 3 w + k: tile t != w in
+    // rising order), then every owner adds the four partials of its tile in wave order
 #pragma unroll
-        for (int a = 0; a < 16; ++a) d1[a] = bias[a];
-        d1 = mfma(w[1], fB[1], mfma(w[0], fB[0], d1));
-        h8 F[2];
+    for (int t = 0; t < NQT; ++t)
+        if (t != w) {
+            float4 (*dst)[64] = pbuf[3 * w + (t < w ? t : t - 1)];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int q = 0; q < 4; ++q)
+                dst[q][lane] = float4{D2[t][4 * q], D2[t][4 * q + 1], D2[t][4 * q + 2],
+                                      D2[t][4 * q + 3]};
+        }
+    __syncthreads();
+    if (w < NQT) {
+        f16x sum = zero16();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 u = (_Float16)d1[8 * s + j];
-                F[s][j] = u > (_Float16)0.f ? u : (_Float16)0.f;
+        for (int src = 0; src < 4; ++src) {
+            if (src == w) {
+                // (NQT is a compile-time bound of t; the wave's own tile is D2[w])
+#pragma unroll
+                for (int t = 0; t < NQT; ++t)
+                    if (t == w) {
+#pragma unroll
+                        for (int a = 0; a < 16; ++a) sum[a] += D2[t][a];
+                    }
+            } else {
+                const float4 (*from)[64] = pbuf[3 * src + (w < src ? w : w - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = from[q][lane];
+                    sum[4 * q] += v.x; sum[4 * q + 1] += v.y;
+                    sum[4 * q + 2] += v.z; sum[4 * q + 3] += v.w;
+                }
             }
-        D2 = mfma(w[3], F[1], mfma(w[2], F[0], D2));
-    }
-    add_rows(D2, b2, hi);
-    round_fp16(D2);
+        }
+        add_rows(sum, b2, hi);
+        round_fp16(sum);
 #pragma unroll
-    for (int a = 0; a < 16; ++a) hT[a] += D2[a];
-    layer_norm(hT, g2, be2, hi);
+        for (int a = 0; a < 16; ++a) hT[a] += sum[a];
+        layer_norm(hT, g2, be2, hi);
+    }
+    __syncthreads();            // the partials' memory is the next layer's keys and values
 }
 
 template <int NHEAD>
 __global__ __launch_bounds__(256, 2) void k_oracle_net_wg(NetArgs P) {
-    __shared__ h8 kv[2][NT][2][64];                 // keys | values: [tile][k-step][lane], 16 KB
+    // 48 KB: during the attention the keys | values of all tiles ([2][tile][k-step][lane] fp16
+    // fragments, 16 KB), during the feed-forward block the partial sums of the hidden split
+    // ([12 slots][4][lane] float4); + 8 KB of h^T fragments of all tiles; two workgroups per CU
+    __shared__ float4 pbuf[12][4][64];
+    __shared__ h8 fbuf[NT][2][64];
+    h8 (*kv)[NT][2][64] = reinterpret_cast<h8 (*)[NT][2][64]>(&pbuf[0][0][0]);
     extern __shared__ __align__(16) float b1_lds[]; // [2][ff], see stage_b1
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // wave w owns token tile w
     const long long row = blockIdx.x;               // one workgroup per streamline
@@ -677,8 +734,17 @@ __global__ __launch_bounds__(256, 2) void k_oracle_net_wg(NetArgs P) {
             to_frags(q, QB);
         }
         const float *b1s = stage_b1(b1_lds, P, layer);      // its barrier also publishes kv
-        if (goes_on) attention_ff_tile<NHEAD>(hT, QB, kv, P, layer, lane, n, hi, b1s);
-        __syncthreads();                            // kv is rewritten by the next layer
+        if (goes_on) {
+            attention_tile<NHEAD>(hT, QB, kv, P, layer, lane, n, hi);
+            // h^T of this tile after LayerNorm 1, as operand fragments, for every wave
+            h8 f[2];
+            to_frags(hT, f);
+            fbuf[w][0][lane] = f[0];
+            fbuf[w][1][lane] = f[1];
+        }
+        __syncthreads();                            // everybody is done with kv as well
+        if (last) ff_hidden_split<1>(hT, fbuf, pbuf, P, layer, lane, hi, w, b1s);
+        else ff_hidden_split<NT>(hT, fbuf, pbuf, P, layer, lane, hi, w, b1s);
     }
 
     if (w == 0) {
