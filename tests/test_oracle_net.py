@@ -171,6 +171,9 @@ def test_oracle_net_packing_layout():
     from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
     assert not FusedOracleNet.supports(TransformerOracle(381, 1, 8, 2, 1e-4))
     assert not FusedOracleNet.supports(TransformerOracle(300, 1, 4, 2, 1e-4))
+    # ... and so does a feed-forward block wider than the kernels' LDS staging of b_1
+    wide = _random_oracle(4, 1, 0, ff=8192 + 32)
+    assert not FusedOracleNet.supports(wide) and FusedOracleNet.supports(_random_oracle(4, 1, 0, ff=8192))
 
 
 @pytest.mark.gpu
