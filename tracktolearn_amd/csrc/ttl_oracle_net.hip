@@ -238,9 +238,6 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
 #pragma unroll
     for (int nt = 0; nt < NQ; ++nt) {
         f16x OT = zero16();
-#if defined(TTL_EXP_NO_ATTENTION)       // timing experiment: scores / softmax / P.V skipped
-        OT = hT[nt];
-#else
 #pragma unroll
         for (int h = 0; h < NHEAD; ++h) {
             // scores S^T [keys x queries] of head h
@@ -289,7 +286,6 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
                 }
             }
         }
-#endif
         // out-projection on the fp16 attention output, residual, LayerNorm 1
         h8 OB[2];
         to_frags(OT, OB);
@@ -312,31 +308,13 @@ __device__ __forceinline__ void encoder_layer(f16x (&hT)[NT], const NetArgs &P, 
     h8 w1a = W1[lane], w1b = W1[64 + lane], w2a = W2[lane], w2b = W2[64 + lane];
     float bias[16];
     load_bias(b1s, 0, hi, bias);
-#if defined(TTL_EXP_NO_FF)                  // timing experiment: one chunk instead of all
-    for (int c = 0; c < 1; ++c) {
-#else
     for (int c = 0; c < P.ff_chunks; ++c) {
-#endif
         // prefetch the next chunk's weights and bias while this one is multiplied
-        // timing experiments (benchmarks/micro/oracle_ff_probe.py + build_variant.py; the
-        // scores of such a build mean nothing): TTL_EXP_FF_SAME_CHUNK re-reads chunk 0 for every
-        // chunk (L1-resident weights), TTL_EXP_FF_NO_LOADS keeps chunk 0's registers and bias
-#if defined(TTL_EXP_FF_NO_LOADS)
-        const h8 n1a = w1a, n1b = w1b, n2a = w2a, n2b = w2b;
-        float nbias[16];
-#pragma unroll
-        for (int a = 0; a < 16; ++a) nbias[a] = bias[a];
-#else
-#if defined(TTL_EXP_FF_SAME_CHUNK)
-        const int cn = 0;
-#else
         const int cn = c + 1 < P.ff_chunks ? c + 1 : c;
-#endif
         const h8 n1a = W1[(long long)cn * 128 + lane], n1b = W1[(long long)cn * 128 + 64 + lane];
         const h8 n2a = W2[(long long)cn * 128 + lane], n2b = W2[(long long)cn * 128 + 64 + lane];
         float nbias[16];
         load_bias(b1s, cn, hi, nbias);
-#endif
         // the tiles' chains side by side: GEMM 1 of every tile (the bias rides in as the
         // accumulator's initial value), the fp16 round + ReLU of every tile, GEMM 2
         f16x d1[NQ];
@@ -679,6 +657,9 @@ __global__ __launch_bounds__(256, 2) void k_oracle_net_wg(NetArgs P) {
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) warm ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        // fold them HERE: left to the scheduler the sixteen results wait (spilled) for the
+        // word's only reader at the end of the kernel
+        asm volatile("" : "+v"(warm));
     }
 
     f16x hT;
