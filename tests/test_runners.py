@@ -383,7 +383,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     Config 4 is shrunk to 262144 streamlines in total for the rehearsal: the
     shard is then the 131072 rows one GPU holds at N = 8."""
     env = dict(os.environ, PYTHONPATH=ROOT, TTL_BENCH_ONE_DEVICE='1',
-               TTL_BENCH_BACKEND='gloo', TTL_BENCH_C4_TOTAL='262144')
+               TTL_BENCH_BACKEND='gloo', TTL_BENCH_C4_TOTAL='262144',
+               TTL_BENCH_C5_TOTAL='16384')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
                           '--windows', '3', '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=1100, env=env)
@@ -417,6 +418,13 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert e2e['collate_first_call_ms'] > 0         # the untimed warm-up collate
     assert line['other_shapes'] == 'N=1 only'       # the `shapes` leg is a one-GPU leg
     assert line['config3_training'] == 'N=1 only'   # and so is the `learner` leg
+    # config 5: every rank trains on its shard, the learner is data-parallel -- the fused
+    # update's gradient exchange (critics' arena beside the actor's backward) ran on both
+    c5 = line['config5']
+    assert 'error' not in c5, c5
+    assert c5['n_actor'] == 8192 and c5['n_actor_total'] == 16384 and c5['data_parallel']
+    assert c5['fused_learner'] and c5['phases_ms_per_step']['update_all_reduce'] > 0
+    assert c5['value'] > 0 and line['config5_value'] == c5['value']
 
 
 @pytest.mark.gpu
