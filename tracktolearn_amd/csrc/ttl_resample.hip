@@ -230,8 +230,16 @@ int ttl_oracle_segments(const float *history, int64_t row_pitch, const int32_t *
     if (lds > 160u * 1024u)
         return fail(TTL_ERR_INVALID, "ttl_oracle_segments: %d points per row exceed the LDS",
                     n_points);
-    HIP_TRY(hipFuncSetAttribute((const void *)k_oracle_segments,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (raised when a call needs more than any before it: the attribute is per device and
+    // process, the call is on the training step's path)
+    static thread_local size_t lds_allowed[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || lds > lds_allowed[dev]) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_oracle_segments,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0 && dev < 64) lds_allowed[dev] = lds;
+    }
     Lin L{};
     if (lin)
         for (int k = 0; k < 9; ++k) L.m[k] = lin[k];
