@@ -403,9 +403,13 @@ TTL_API int ttl_peaks_from_sh(const float *sh, int64_t n_voxels, int32_t n_coef,
 
 /* TractOracle-Net forward (TrackToLearn/oracles/transformer_oracle.py:77-92 under the
  * autocast of oracles/oracle.py:76): scores[i] = sigmoid(head(encoder(embed([CLS; dirs[i]]))[0]))
- * for n sequences of 127 segment vectors, ONE launch, one wavefront per streamline
- * (csrc/ttl_oracle_net.hip).  d_model 32, 128 tokens, n_head in {1, 2, 4}, ReLU post-norm
- * layers, ff_dim a multiple of 32.  The weights come packed by
+ * for n sequences of 127 segment vectors, ONE launch (csrc/ttl_oracle_net.hip): one
+ * workgroup per streamline for n <= 512, one wavefront per streamline above (the environment
+ * variable TTL_ORACLE_NET_WG = 1 / 0 forces the first / the second).  Each kernel is
+ * deterministic and scores a row independently of its batch; the two agree to the rounding of
+ * the fp16 score (the order of one float32 sum differs).  d_model 32, 128 tokens, n_head in
+ * {1, 2, 4}, ReLU post-norm layers, ff_dim a multiple of 32, at most 8192 (TTL_ERR_UNSUPPORTED
+ * otherwise).  The weights come packed by
  * tracktolearn_amd/oracles/fused_net.py:pack_oracle_net (fp16 MFMA fragments in the k order an
  * accumulator tile presents, per-row vectors in accumulator row order):
  *   packed_half  [n_layers][8 + 4 ff_dim / 32][64][8] f16: W_q, W_k, W_v, W_o, W_1 chunks, W_2 chunks
