@@ -874,6 +874,23 @@ def main(argv=None):
                                           'train_rows_per_step', 'train_streamline_steps_per_s',
                                           'phases_ms_per_step', 'oracle_rows_scored_per_step',
                                           'oracle_batches_per_step') if k in whole}
+                # TractOracle-Net alone (the checkpoint's architecture, random weights): the
+                # batch a training step scores and a large one, against the reference's
+                # formulation (the PyTorch module under autocast) at the large one
+                from benchmarks.bench_oracle_net import measure as oracle_net_measure
+                torch.cuda.empty_cache()
+                nets = oracle_net_measure([256], with_module=False, device=device) + \
+                    oracle_net_measure([16384], with_module=True, device=device)
+                big = nets[-1]
+                c5['oracle_net'] = {
+                    'per_batch': nets,
+                    'roofline': {'bound': 'mfma', 'kernel': 'k_oracle_net<4> (16384 streamlines)',
+                                 'achieved': big['fused_TFLOPs_issued'], 'peak': 2500.0,
+                                 'unit': 'TFLOP/s', 'frac': big['fused_frac_of_fp16_mfma_peak'],
+                                 'traffic': None, 'dtype': 'f16',
+                                 'how': 'FLOP the kernel issues (119.9 MFLOP per streamline; the '
+                                        'module: 146.8) / wall clock of 5 launches / the dense '
+                                        'fp16 MFMA peak'}}
             out['config5'] = c5
         except Exception as exc:
             out['config5'] = {'error': repr(exc)}
@@ -1085,6 +1102,9 @@ def main(argv=None):
         # shows them without opening the nested objects
         def _get(d, *keys):
             for k in keys:
+                if isinstance(d, list) and isinstance(k, int) and d:
+                    d = d[k]
+                    continue
                 if not isinstance(d, dict) or k not in d:
                     return None
                 d = d[k]
@@ -1097,6 +1117,9 @@ def main(argv=None):
             'config5_train_step_ms': _get(line, 'config5', 'train_step_ms_max_over_ranks'),
             'config5_update_ms': _get(line, 'config5', 'update_ms'),
             'config5_value': _get(line, 'config5', 'value'),
+            'oracle_net_16384_ms': _get(line, 'config5', 'oracle_net', 'per_batch', -1,
+                                        'fused_ms'),
+            'oracle_net_frac_fp16_mfma': _get(line, 'config5', 'oracle_net', 'roofline', 'frac'),
             'config4_step_only_value': _get(line, 'config4', 'step_only', 'value'),
             'config4_end_to_end_value': _get(line, 'config4', 'end_to_end', 'value_end_to_end'),
             'roofline_hbm_regime_frac': _get(line, 'roofline_hbm_regime', 'frac'),

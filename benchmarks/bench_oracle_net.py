@@ -47,32 +47,43 @@ def kernel_name(rows):
     return 'workgroup per streamline' if wg else 'wavefront per streamline'
 
 
-def main():
+def measure(rows_list, with_module=True, device='cuda'):
+    """One dict per batch size (bench.py's `config5.oracle_net`, and the lines this
+    script prints)."""
     from tracktolearn_amd.oracles.fused_net import FusedOracleNet
     from tracktolearn_amd.oracles.transformer_oracle import TransformerOracle
-    rows_list = [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 4096, 16384]
     torch.manual_seed(0)
-    model = TransformerOracle(381, 1, 4, 4, 1e-4).cuda().eval()
+    model = TransformerOracle(381, 1, 4, 4, 1e-4).to(device).eval()
     net = FusedOracleNet(model)
     full, issued = flop_per_streamline(4, 2048)
+    out = []
     for rows in rows_list:
-        dirs = torch.randn(rows, 127, 3, device='cuda') * 0.3
+        dirs = torch.randn(rows, 127, 3, device=device) * 0.3
 
         def module():
             with torch.no_grad(), torch.autocast('cuda'):
                 for lo in range(0, rows, 4096):             # OracleSingleton's batches
                     model(dirs[lo:lo + 4096])
         t_fused = timeit(lambda: net(dirs), 20 if rows <= 4096 else 5)
-        t_mod = timeit(module, 5 if rows <= 4096 else 2)
-        print(json.dumps({
-            'rows': rows, 'kernel': kernel_name(rows),
-            'fused_ms': round(t_fused * 1e3, 4), 'module_autocast_ms': round(t_mod * 1e3, 3),
-            'speedup': round(t_mod / t_fused, 1),
+        line = {
+            'rows': rows, 'kernel': kernel_name(rows), 'fused_ms': round(t_fused * 1e3, 4),
             'fused_TFLOPs_issued': round(rows * issued / t_fused / 1e12, 1),
             'fused_frac_of_fp16_mfma_peak': round(rows * issued / t_fused / 1e12 / FP16_MFMA_PEAK_TF, 4),
-            'module_TFLOPs': round(rows * full / t_mod / 1e12, 1),
             'mflop_per_streamline_module': round(full / 1e6, 1),
-            'mflop_per_streamline_issued': round(issued / 1e6, 1)}), flush=True)
+            'mflop_per_streamline_issued': round(issued / 1e6, 1)}
+        if with_module:
+            t_mod = timeit(module, 5 if rows <= 4096 else 2)
+            line.update(module_autocast_ms=round(t_mod * 1e3, 3),
+                        speedup=round(t_mod / t_fused, 1),
+                        module_TFLOPs=round(rows * full / t_mod / 1e12, 1))
+        out.append(line)
+    return out
+
+
+def main():
+    rows_list = [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 4096, 16384]
+    for rows in rows_list:
+        print(json.dumps(measure([rows])[0]), flush=True)
 
 
 if __name__ == '__main__':

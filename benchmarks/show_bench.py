@@ -51,6 +51,12 @@ def training(name, t):
         if 'oracle_rows_scored_per_step' in t:
             print(f"   oracle: {t['oracle_rows_scored_per_step']:.0f} rows scored per step in "
                   f"{t['oracle_batches_per_step']:.2f} batches ({t.get('oracle_net')})")
+        on = t.get('oracle_net')
+        if on:
+            print('   oracle network alone: ' + ', '.join(
+                f"{b['rows']} rows {b['fused_ms']:.3f} ms" for b in on['per_batch'])
+                + f" = {on['roofline']['frac']:.3f} of the fp16 MFMA peak; module "
+                f"{on['per_batch'][-1].get('module_autocast_ms')} ms")
         w = t.get('whole_batch_on_one_gpu')
         if w:
             print(f"   whole batch on one GPU ({w['n_actor']}): {w['train_step_ms']:.2f} ms per step, "

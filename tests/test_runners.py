@@ -500,6 +500,14 @@ def test_bench_config5_leg():
     # bonus the ones that stopped: more rows scored than one batch per episode
     assert c5['oracle_rows_scored_per_step'] > 20
     assert c5['whole_batch_on_one_gpu']['n_actor'] == 32768
+    # the network alone: the batch a step scores (one workgroup per streamline) and a large
+    # one (one wavefront per streamline) with its fraction of the fp16 MFMA peak
+    on = c5['oracle_net']
+    assert [b['rows'] for b in on['per_batch']] == [256, 16384]
+    assert on['per_batch'][0]['kernel'].startswith('workgroup') and \
+        on['per_batch'][1]['kernel'].startswith('wavefront')
+    assert 0.05 < on['roofline']['frac'] < 1.0 and on['roofline']['dtype'] == 'f16'
+    assert line['oracle_net_16384_ms'] == on['per_batch'][1]['fused_ms']
     assert line['config5_value'] == c5['value']
 
 
