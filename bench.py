@@ -882,7 +882,7 @@ def main(argv=None):
                 nets = oracle_net_measure([256], with_module=False, device=device) + \
                     oracle_net_measure([16384], with_module=True, device=device)
                 big = nets[-1]
-                c5['oracle_net'] = {
+                c5['oracle_net_alone'] = {
                     'per_batch': nets,
                     'roofline': {'bound': 'mfma', 'kernel': 'k_oracle_net<4> (16384 streamlines)',
                                  'achieved': big['fused_TFLOPs_issued'], 'peak': 2500.0,
@@ -1117,9 +1117,9 @@ def main(argv=None):
             'config5_train_step_ms': _get(line, 'config5', 'train_step_ms_max_over_ranks'),
             'config5_update_ms': _get(line, 'config5', 'update_ms'),
             'config5_value': _get(line, 'config5', 'value'),
-            'oracle_net_16384_ms': _get(line, 'config5', 'oracle_net', 'per_batch', -1,
+            'oracle_net_16384_ms': _get(line, 'config5', 'oracle_net_alone', 'per_batch', -1,
                                         'fused_ms'),
-            'oracle_net_frac_fp16_mfma': _get(line, 'config5', 'oracle_net', 'roofline', 'frac'),
+            'oracle_net_frac_fp16_mfma': _get(line, 'config5', 'oracle_net_alone', 'roofline', 'frac'),
             'config4_step_only_value': _get(line, 'config4', 'step_only', 'value'),
             'config4_end_to_end_value': _get(line, 'config4', 'end_to_end', 'value_end_to_end'),
             'roofline_hbm_regime_frac': _get(line, 'roofline_hbm_regime', 'frac'),

@@ -29,7 +29,7 @@ def flop_per_streamline(n_layers, ff, d=32, tokens=128, issued_last_layer_tokens
 
 
 def timeit(fn, reps):
-    for _ in range(2):
+    for _ in range(3):
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -64,7 +64,7 @@ def measure(rows_list, with_module=True, device='cuda'):
             with torch.no_grad(), torch.autocast('cuda'):
                 for lo in range(0, rows, 4096):             # OracleSingleton's batches
                     model(dirs[lo:lo + 4096])
-        t_fused = timeit(lambda: net(dirs), 20 if rows <= 4096 else 5)
+        t_fused = timeit(lambda: net(dirs), 20 if rows <= 4096 else 8)
         line = {
             'rows': rows, 'kernel': kernel_name(rows), 'fused_ms': round(t_fused * 1e3, 4),
             'fused_TFLOPs_issued': round(rows * issued / t_fused / 1e12, 1),

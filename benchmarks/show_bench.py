@@ -51,7 +51,7 @@ def training(name, t):
         if 'oracle_rows_scored_per_step' in t:
             print(f"   oracle: {t['oracle_rows_scored_per_step']:.0f} rows scored per step in "
                   f"{t['oracle_batches_per_step']:.2f} batches ({t.get('oracle_net')})")
-        on = t.get('oracle_net')
+        on = t.get('oracle_net_alone')
         if on:
             print('   oracle network alone: ' + ', '.join(
                 f"{b['rows']} rows {b['fused_ms']:.3f} ms" for b in on['per_batch'])

@@ -502,7 +502,7 @@ def test_bench_config5_leg():
     assert c5['whole_batch_on_one_gpu']['n_actor'] == 32768
     # the network alone: the batch a step scores (one workgroup per streamline) and a large
     # one (one wavefront per streamline) with its fraction of the fp16 MFMA peak
-    on = c5['oracle_net']
+    on = c5['oracle_net_alone']
     assert [b['rows'] for b in on['per_batch']] == [256, 16384]
     assert on['per_batch'][0]['kernel'].startswith('workgroup') and \
         on['per_batch'][1]['kernel'].startswith('wavefront')
