@@ -873,7 +873,8 @@ def main(argv=None):
                     k: whole[k] for k in ('n_actor', 'update_ms', 'train_step_ms',
                                           'train_rows_per_step', 'train_streamline_steps_per_s',
                                           'phases_ms_per_step', 'oracle_rows_scored_per_step',
-                                          'oracle_batches_per_step') if k in whole}
+                                          'oracle_batches_per_step', 'policy_forward')
+                    if k in whole}
                 # TractOracle-Net alone (the checkpoint's architecture, random weights): the
                 # batch a training step scores and a large one, against the reference's
                 # formulation (the PyTorch module under autocast) at the large one

@@ -309,6 +309,19 @@ def measure(config='c3', n_actor=None, hidden='1024-1024', batch=4096, steps=Non
         out['oracle_batches_per_step'] = rows['batches'] / steps
     out['phases_ms_per_step'] = phases
     out['phases_rows_per_step'] = units / steps
+    # the policy phase against the fp32 MFMA peak: the actor's forward on the rows of a step
+    # (2 M N K per layer, head included), summed over the episode / the summed phase time
+    if phases.get('policy'):
+        dims = [W] + [int(h) for h in str(hidden).split('-')] + [6]
+        macs = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+        tf = 2.0 * macs * units / (tot['policy'] * 1e-3) / 1e12
+        out['policy_forward'] = {'bound': 'mfma', 'achieved': tf, 'peak': FP32_MFMA_PEAK_TF,
+                                 'unit': 'TFLOP/s', 'frac': tf / FP32_MFMA_PEAK_TF,
+                                 'dtype': 'f32', 'rows_per_step': units / steps,
+                                 'how': 'actor forward FLOP of the rows stepped / policy phase time '
+                                        '(HIP events): two hipBLASLt GEMMs with bias + ReLU '
+                                        'epilogue whose row count changes every step, and the '
+                                        'head as one ttl_thin_forward launch'}
     if tmp is not None:
         from tracktolearn_amd.oracles.oracle import OracleSingleton
         OracleSingleton.reset()

@@ -48,6 +48,10 @@ def training(name, t):
               + (f"; graphed update: step {g['train_step_ms']:.2f} ms, update {g['update_ms']:.2f} ms"
                  if g else ''))
         print('   phases (ms): ' + ', '.join(f'{k} {v:.3f}' for k, v in ph.items()))
+        pf = t.get('policy_forward')
+        if pf:
+            print(f"   policy forward: {pf['achieved']:.1f} TF/s = {pf['frac']:.3f} of the fp32 MFMA peak "
+                  f"at {pf['rows_per_step']:.0f} rows per step")
         if 'oracle_rows_scored_per_step' in t:
             print(f"   oracle: {t['oracle_rows_scored_per_step']:.0f} rows scored per step in "
                   f"{t['oracle_batches_per_step']:.2f} batches ({t.get('oracle_net')})")

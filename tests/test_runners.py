@@ -500,6 +500,7 @@ def test_bench_config5_leg():
     # bonus the ones that stopped: more rows scored than one batch per episode
     assert c5['oracle_rows_scored_per_step'] > 20
     assert c5['whole_batch_on_one_gpu']['n_actor'] == 32768
+    assert 0 < c5['policy_forward']['frac'] < 1 and c5['policy_forward']['dtype'] == 'f32'
     # the network alone: the batch a step scores (one workgroup per streamline) and a large
     # one (one wavefront per streamline) with its fraction of the fp16 MFMA peak
     on = c5['oracle_net_alone']
